@@ -1,0 +1,264 @@
+/*
+ * skinrt.h — C ABI of libskinrt: MI355X-native per-frame skinned-scene evaluation.
+ *
+ * Drop-in boundary for ONE path of fifth-light/renderer: animation
+ * channel sampling -> node world-transform propagation -> joint palette -> morph
+ * blending + linear-blend skinning (+ per-instance AABB) over a crowd of independent
+ * instances of one rig.  The reference has no FFI for this path (it is plain Rust
+ * types); every entry point below names the reference item it stands in for, as
+ * `path:line` under /root/reference/crates/.
+ *
+ * Conventions
+ *   - every call returns int: 0 = SKINRT_OK, negative = SKINRT_E_*; nothing aborts or
+ *     throws across the boundary; skinrt_last_error() gives the text of the last failure
+ *     on the calling thread.
+ *   - host input pointers are borrowed for the duration of the call only.
+ *   - handles are opaque, owned by the library until the matching destroy call.
+ *   - all matrices are column-major float[16], as glam `Mat4::to_cols_array`
+ *     (renderer-asset/src/loader/mod.rs:68-75).  Node/root matrices must be affine
+ *     (last row 0,0,0,1): glTF requires it and the kernels store 3x4.
+ *   - a ctx is bound to one HIP device and one stream; calls on one crowd must not
+ *     overlap (the reference calls this path from one render thread, renderer/src/state.rs:236).
+ *   - getters return DEVICE pointers valid until the crowd is destroyed; contents are
+ *     defined after skinrt_evaluate + skinrt_synchronize.
+ */
+#ifndef SKINRT_H
+#define SKINRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKINRT_ABI_VERSION 1
+
+/* ---- error codes ---------------------------------------------------------------- */
+#define SKINRT_OK 0
+#define SKINRT_E_INVALID (-1)     /* bad argument / malformed rig (reference: panics, loader/gltf/mod.rs:1050,:272) */
+#define SKINRT_E_DEVICE (-2)      /* HIP runtime error (no GPU, launch failure, ...) */
+#define SKINRT_E_NOMEM (-3)       /* host or device allocation failed */
+#define SKINRT_E_NONAFFINE (-4)   /* a node / root matrix has a last row other than 0,0,0,1 */
+#define SKINRT_E_RANGE (-5)       /* index out of range (joint, node, clip, instance) */
+#define SKINRT_E_LIMIT (-6)       /* reference_limits=1 and joints > 128 (renderer/src/renderer/uniform/skin.rs:10,40,60) */
+
+/* ---- enums ----------------------------------------------------------------------- */
+/* AnimationSampler::{Translation,Rotation,Scale} — renderer-asset/src/animation.rs:23-27 */
+#define SKINRT_PATH_TRANSLATION 0
+#define SKINRT_PATH_ROTATION 1
+#define SKINRT_PATH_SCALE 2
+/* AnimationKeyFrames::{Linear,Step,CubicSpline} — renderer-asset/src/animation.rs:15-20 */
+#define SKINRT_INTERP_LINEAR 0
+#define SKINRT_INTERP_STEP 1
+#define SKINRT_INTERP_CUBICSPLINE 2
+
+/* stages of skinrt_evaluate (bit mask) */
+#define SKINRT_STAGE_POSE 1u      /* sample + propagate + palette (a2-a9) */
+#define SKINRT_STAGE_SKIN 2u      /* morph + linear-blend skinning (a10, a13) */
+#define SKINRT_STAGE_AABB 4u      /* per-instance bounds of skinned positions (a14); needs SKIN */
+#define SKINRT_STAGE_ALL 7u
+
+/* vertex layouts of skinrt_export_interleaved — renderer/src/renderer/buffer/vertex.rs */
+#define SKINRT_LAYOUT_COLOR_SKIN 0    /* ColorSkinVertex, 68 B  (:60-69) */
+#define SKINRT_LAYOUT_TEXTURE_SKIN 1  /* TextureSkinVertex, 60 B (:82-91) */
+
+#define SKINRT_MAX_JOINTS_REFERENCE 128 /* MAX_JOINTS, renderer/src/renderer/uniform/skin.rs:10 */
+#define SKINRT_SKIN_MATRIX_BYTES 112    /* SkinMatrix{[[f32;4];4],[[f32;4];3]}, uniform/skin.rs:12-17 */
+
+typedef struct skinrt_ctx skinrt_ctx;
+typedef struct skinrt_rig skinrt_rig;
+typedef struct skinrt_crowd skinrt_crowd;
+
+/* ---- configuration ----------------------------------------------------------------
+ * Stands in for the reference's env/feature configuration (SURVEY.md §5 "Config"). */
+typedef struct skinrt_config {
+    uint32_t struct_size;       /* = sizeof(skinrt_config) */
+    int32_t device;             /* HIP device ordinal */
+    /* 1: Interpolate::cubic_spline exactly as written, t2 = t.powi(3)
+     *    (renderer-asset/src/animation.rs:57); 0: glTF-spec Hermite basis (t2 = t*t). */
+    uint32_t cubic_quirk;
+    /* 1: normal/tangent outputs are normalize()d as the outline shader variants do
+     *    (renderer/src/shader/shader.wgsl:217-218); 0: un-normalised (:162-163,:186-187). */
+    uint32_t normalize_outputs;
+    /* 1: reject rigs the reference cannot render (joints > 128, weight sets > 1). */
+    uint32_t reference_limits;
+    uint32_t reserved[3];
+} skinrt_config;
+
+/* ---- flat rig ("loader output", SURVEY.md §8a rows a1,a5-a8,a11,a13) ---------------- */
+
+/* One AnimationChannelAsset{sampler,length,target_id} — renderer-asset/src/animation.rs:29-34,
+ * keyframes flattened to SoA (time[], value[]) from AnimationKeyFrame<T> (:8-12). */
+typedef struct skinrt_channel_desc {
+    uint32_t target_node;    /* flat node index of target_id's node */
+    uint8_t path;            /* SKINRT_PATH_* */
+    uint8_t interpolation;   /* SKINRT_INTERP_* */
+    uint16_t reserved;
+    uint32_t key_count;      /* >= 1 */
+    const float* times;      /* [key_count], non-decreasing */
+    /* width w = 4 for rotation (x,y,z,w) else 3.
+     * LINEAR/STEP: [key_count][w].  CUBICSPLINE: [key_count][3][w] = (in, value, out),
+     * the order of AnimationKeyFrames::CubicSpline (animation.rs:18-19). */
+    const float* values;
+} skinrt_channel_desc;
+
+/* One AnimationAsset{name,channels} — renderer-asset/src/animation.rs:36-40 */
+typedef struct skinrt_clip_desc {
+    uint32_t channel_count;
+    const skinrt_channel_desc* channels;
+} skinrt_clip_desc;
+
+/* One PrimitiveAssetMorphTarget{position,normal,tangent} — renderer-asset/src/primitive.rs:33-38.
+ * indices == NULL: dense, count == vertex_count (the loader's form).  indices != NULL:
+ * compacted form, arrays hold only the touched vertices (strictly increasing indices). */
+typedef struct skinrt_morph_target_desc {
+    uint32_t count;
+    const uint32_t* indices;
+    const float* position;   /* [count][3], NULL = zeros (loader: empty Vec) */
+    const float* normal;     /* [count][3], NULL = zeros */
+    const float* tangent;    /* [count][tangent_stride], NULL = zeros; only xyz is used */
+} skinrt_morph_target_desc;
+
+typedef struct skinrt_rig_desc {
+    uint32_t struct_size;    /* = sizeof(skinrt_rig_desc) */
+
+    /* nodes: NodeAsset tree (renderer-asset/src/node.rs:89-99) flattened DFS pre-order over
+     * SceneAsset.nodes then children (loader/gltf/mod.rs:1168-1217); parent[n] < n, -1 = root. */
+    uint32_t node_count;
+    const int32_t* parent;       /* [N] */
+    const float* translation;    /* [N][3]  DecomposedTransform (node.rs:13-17) */
+    const float* rotation;       /* [N][4]  x,y,z,w — used un-normalised, as glam does */
+    const float* scale;          /* [N][3] */
+    const float* matrix;         /* [N][16] or NULL; NodeTransform::Matrix (node.rs:29-33) */
+    const uint8_t* has_matrix;   /* [N] or NULL; 1 = node uses matrix[n] */
+
+    /* skin: SkinAsset{inverse_bind_matrices,joint_ids} — renderer-asset/src/skin.rs:5-11 */
+    uint32_t joint_count;
+    const uint32_t* joint_node;  /* [J] flat node index of each joint */
+    const float* inverse_bind;   /* [J][16] or NULL = identity (loader/gltf/mod.rs:1139-1145) */
+
+    /* animations: Vec<AnimationAsset> */
+    uint32_t clip_count;
+    const skinrt_clip_desc* clips;
+
+    /* mesh: PrimitiveAssetAttributes — renderer-asset/src/primitive.rs:22-31 (all primitives of
+     * the skinned mesh concatenated). */
+    uint32_t vertex_count;
+    const float* position;       /* [V][3] */
+    const float* normal;         /* [V][3] */
+    const float* tangent;        /* [V][tangent_stride]; only xyz is used (shader.wgsl:90) */
+    uint32_t tangent_stride;     /* 3 or 4 (asset side stores [f32;4], primitive.rs:26) */
+    uint32_t set_count;          /* K >= 1 JOINTS_n/WEIGHTS_n sets; the reference shader reads set 0 */
+    const uint16_t* const* joints;  /* [K] -> [V][4]  Joints = Vec<[u16;4]> (primitive.rs:19) */
+    const float* const* weights;    /* [K] -> [V][4]  Weights = Vec<[f32;4]> (primitive.rs:20) */
+
+    /* morph targets + MeshAsset.weights (renderer-asset/src/mesh.rs:7) */
+    uint32_t target_count;
+    const skinrt_morph_target_desc* targets;
+    const float* default_weights;   /* [M] or NULL = zeros */
+} skinrt_rig_desc;
+
+/* ---- lifecycle --------------------------------------------------------------------- */
+
+/* Library/ABI version (SKINRT_ABI_VERSION). No reference counterpart. */
+int skinrt_abi_version(void);
+
+/* Text of the last error raised on the calling thread ("" if none).
+ * Stands in for GltfLoaderError's Display impl (loader/gltf/mod.rs:78-173). */
+const char* skinrt_last_error(void);
+
+/* Create a context on config->device with its own HIP stream.
+ * Replaces wgpu device/queue acquisition for this path (renderer/src/state.rs:94-127). */
+int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx);
+int skinrt_destroy_ctx(skinrt_ctx* ctx);
+
+/* Validate, compile (vertex tiles, tile-local joint lists, per-vertex morph lists,
+ * depth levels) and upload a rig.  Replaces VertexBuffer::new (renderer/buffer/vertex.rs:110-121)
+ * and the one-time walk of (Vec<SceneAsset>, Vec<AnimationAsset>) (loader/gltf/mod.rs:199). */
+int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig** out_rig);
+int skinrt_destroy_rig(skinrt_rig* rig);
+
+/* Allocate per-instance state and output buffers for `instances` copies of `rig`.
+ * Replaces one SkinUniformBuffer::new per entity (renderer/uniform/skin.rs:39-57). */
+int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, skinrt_crowd** out_crowd);
+int skinrt_destroy_crowd(skinrt_crowd* crowd);
+
+/* ---- per-frame inputs ----------------------------------------------------------------- */
+
+/* Per-instance animation clock tau[I] (seconds, already wrapped by the caller) and clip
+ * index clip_id[I] (NULL = clip 0; UINT32_MAX = rest pose).  Keyframe search rule: SURVEY.md §8a a4. */
+int skinrt_set_clocks(skinrt_crowd* crowd, const float* tau, const uint32_t* clip_id);
+/* Per-instance morph weights w[I][M] (NodeAsset.weights override, node.rs:98); NULL restores
+ * the rig's default weights for every instance. */
+int skinrt_set_morph_weights(skinrt_crowd* crowd, const float* weights);
+/* Per-instance root placement m[I][16] (pre-multiplies every scene root); NULL = none.
+ * Replaces InstanceUniformBuffer.transform for crowd placement (renderer/uniform/transform.rs:17-20). */
+int skinrt_set_root_transforms(skinrt_crowd* crowd, const float* matrices);
+
+/* ---- evaluation ------------------------------------------------------------------------ */
+
+/* Enqueue the selected stages on the ctx stream (asynchronous).  This is the body the
+ * reference leaves empty at Entity::render (renderer/src/client/entity/mod.rs:34). */
+int skinrt_evaluate(skinrt_crowd* crowd, uint32_t stages_mask);
+/* Block until everything enqueued on the ctx stream has finished. */
+int skinrt_synchronize(skinrt_ctx* ctx);
+/* Device time of the last evaluate's kernels in ms (HIP events on the ctx stream):
+ * ms[0]=pose, ms[1]=skin+morph, ms[2]=aabb reduce, ms[3]=total span.  Synchronises. */
+int skinrt_last_stage_ms(skinrt_crowd* crowd, float ms[4]);
+/* The ctx's hipStream_t, for callers that order their own work against it. */
+int skinrt_get_stream(skinrt_ctx* ctx, void** out_stream);
+
+/* ---- outputs (device pointers) --------------------------------------------------------- */
+/* Skinned world-space positions / normals / tangents, each [I][V][3] f32
+ * (shader.wgsl:159-163,:223-226: skin_matrix * vec4(position,1), normal_matrix * normal/tangent). */
+int skinrt_get_positions(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+int skinrt_get_normals(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+int skinrt_get_tangents(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+/* Per-instance bounds [I][2][3] f32 (min xyz, max xyz).  No reference counterpart (a14). */
+int skinrt_get_aabbs(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+/* Joint palette [I][J][24] f32: 3 rows x 4 of the joint matrix (row r = m[r][0..3] incl.
+ * translation), then 3 rows x 4 of the normal matrix (4th of each row = 0).
+ * Same numbers as SkinMatrix (uniform/skin.rs:12-17), transposed to rows; see
+ * skinrt_export_skin_uniform for the reference byte layout. */
+int skinrt_get_palette(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+/* Node world matrices [I][N][12] f32, 3 rows x 4 (the Mat4's first three rows). */
+int skinrt_get_world(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+/* Selected keyframe per (instance, channel of the instance's clip): [I][Cmax] u32, Cmax =
+ * largest clip channel count; entries past the clip's channel count are UINT32_MAX. */
+int skinrt_get_keyframe_index(skinrt_crowd* crowd, uint32_t** out_dev, uint64_t* out_count);
+
+/* Copy `bytes` from a device pointer returned above to host memory (synchronises the ctx). */
+int skinrt_download(skinrt_ctx* ctx, const void* dev_src, void* host_dst, uint64_t bytes);
+
+/* ---- reference-layout exports (host destinations) ---------------------------------------- */
+/* One instance's palette as the reference uploads it: 128 x SkinMatrix (112 B each: mat4
+ * column-major, then 3 x vec4 normal columns padded with 0), entries >= J zero
+ * (uniform/skin.rs:41-50; shader.wgsl:70-77).  Requires J <= 128. dst: 14336 bytes. */
+int skinrt_export_skin_uniform(skinrt_crowd* crowd, uint32_t instance, void* dst);
+/* One instance's vertices in ColorSkinVertex (68 B) or TextureSkinVertex (60 B) layout
+ * (buffer/vertex.rs:60-102): position/normal/tangent = skinned outputs, joint_index =
+ * 0,0,0,0 and joint_weight = 1,0,0,0 are NOT emitted — the rig's set-0 indices/weights are
+ * passed through so the reference shader can re-skin or ignore them; color (4 f32) or
+ * tex_coords (2 f32) are copied from `attr` ([V][4] or [V][2], NULL = zeros). dst: V*stride bytes. */
+int skinrt_export_interleaved(skinrt_crowd* crowd, uint32_t instance, uint32_t layout,
+                              const float* attr, void* dst);
+
+/* ---- rig introspection (what upload compiled; used by tests and the bench roofline) ------- */
+typedef struct skinrt_rig_info {
+    uint32_t node_count, joint_count, vertex_count, set_count, target_count, clip_count;
+    uint32_t level_count;          /* depth levels of the node forest */
+    uint32_t tile_count;           /* vertex tiles */
+    uint32_t tile_vertices;        /* vertices per tile */
+    uint32_t max_tile_joints;      /* largest tile-local joint list */
+    uint32_t lds_tiles;            /* tiles whose joint list is LDS-staged (others gather from L2) */
+    uint32_t max_channels;         /* Cmax */
+    uint64_t morph_entries;        /* nonzero (vertex,target) pairs kept after compaction */
+    uint64_t device_bytes;         /* bytes of device memory the rig occupies */
+} skinrt_rig_info;
+int skinrt_get_rig_info(skinrt_rig* rig, skinrt_rig_info* out_info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKINRT_H */
