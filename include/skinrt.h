@@ -33,6 +33,7 @@ extern "C" {
 #endif
 
 #define SKINRT_ABI_VERSION 1
+#define SKINRT_API __attribute__((visibility("default")))
 
 /* ---- error codes ---------------------------------------------------------------- */
 #define SKINRT_OK 0
@@ -83,7 +84,14 @@ typedef struct skinrt_config {
     uint32_t normalize_outputs;
     /* 1: reject rigs the reference cannot render (joints > 128, weight sets > 1). */
     uint32_t reference_limits;
-    uint32_t reserved[3];
+    /* 1: the skinning kernel uses no fused multiply-add, so positions/normals/tangents are
+     *    bit-equal to the fp32 CPU restatement (oracle/); 0: FMA in the same association
+     *    (within 1e-5 rel / 1e-6 abs).  Pose stages are always contraction-free. */
+    uint32_t exact_arithmetic;
+    /* 0: choose per rig; 1: wavefront-per-instance pose kernel; 2: split pose kernels
+     *    (sample / lane-per-instance propagate / palette) used for very deep or large rigs. */
+    uint32_t pose_path;
+    uint32_t reserved[1];
 } skinrt_config;
 
 /* ---- flat rig ("loader output", SURVEY.md §8a rows a1,a5-a8,a11,a13) ---------------- */
@@ -159,91 +167,6 @@ typedef struct skinrt_rig_desc {
     const float* default_weights;   /* [M] or NULL = zeros */
 } skinrt_rig_desc;
 
-/* ---- lifecycle --------------------------------------------------------------------- */
-
-/* Library/ABI version (SKINRT_ABI_VERSION). No reference counterpart. */
-int skinrt_abi_version(void);
-
-/* Text of the last error raised on the calling thread ("" if none).
- * Stands in for GltfLoaderError's Display impl (loader/gltf/mod.rs:78-173). */
-const char* skinrt_last_error(void);
-
-/* Create a context on config->device with its own HIP stream.
- * Replaces wgpu device/queue acquisition for this path (renderer/src/state.rs:94-127). */
-int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx);
-int skinrt_destroy_ctx(skinrt_ctx* ctx);
-
-/* Validate, compile (vertex tiles, tile-local joint lists, per-vertex morph lists,
- * depth levels) and upload a rig.  Replaces VertexBuffer::new (renderer/buffer/vertex.rs:110-121)
- * and the one-time walk of (Vec<SceneAsset>, Vec<AnimationAsset>) (loader/gltf/mod.rs:199). */
-int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig** out_rig);
-int skinrt_destroy_rig(skinrt_rig* rig);
-
-/* Allocate per-instance state and output buffers for `instances` copies of `rig`.
- * Replaces one SkinUniformBuffer::new per entity (renderer/uniform/skin.rs:39-57). */
-int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, skinrt_crowd** out_crowd);
-int skinrt_destroy_crowd(skinrt_crowd* crowd);
-
-/* ---- per-frame inputs ----------------------------------------------------------------- */
-
-/* Per-instance animation clock tau[I] (seconds, already wrapped by the caller) and clip
- * index clip_id[I] (NULL = clip 0; UINT32_MAX = rest pose).  Keyframe search rule: SURVEY.md §8a a4. */
-int skinrt_set_clocks(skinrt_crowd* crowd, const float* tau, const uint32_t* clip_id);
-/* Per-instance morph weights w[I][M] (NodeAsset.weights override, node.rs:98); NULL restores
- * the rig's default weights for every instance. */
-int skinrt_set_morph_weights(skinrt_crowd* crowd, const float* weights);
-/* Per-instance root placement m[I][16] (pre-multiplies every scene root); NULL = none.
- * Replaces InstanceUniformBuffer.transform for crowd placement (renderer/uniform/transform.rs:17-20). */
-int skinrt_set_root_transforms(skinrt_crowd* crowd, const float* matrices);
-
-/* ---- evaluation ------------------------------------------------------------------------ */
-
-/* Enqueue the selected stages on the ctx stream (asynchronous).  This is the body the
- * reference leaves empty at Entity::render (renderer/src/client/entity/mod.rs:34). */
-int skinrt_evaluate(skinrt_crowd* crowd, uint32_t stages_mask);
-/* Block until everything enqueued on the ctx stream has finished. */
-int skinrt_synchronize(skinrt_ctx* ctx);
-/* Device time of the last evaluate's kernels in ms (HIP events on the ctx stream):
- * ms[0]=pose, ms[1]=skin+morph, ms[2]=aabb reduce, ms[3]=total span.  Synchronises. */
-int skinrt_last_stage_ms(skinrt_crowd* crowd, float ms[4]);
-/* The ctx's hipStream_t, for callers that order their own work against it. */
-int skinrt_get_stream(skinrt_ctx* ctx, void** out_stream);
-
-/* ---- outputs (device pointers) --------------------------------------------------------- */
-/* Skinned world-space positions / normals / tangents, each [I][V][3] f32
- * (shader.wgsl:159-163,:223-226: skin_matrix * vec4(position,1), normal_matrix * normal/tangent). */
-int skinrt_get_positions(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
-int skinrt_get_normals(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
-int skinrt_get_tangents(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
-/* Per-instance bounds [I][2][3] f32 (min xyz, max xyz).  No reference counterpart (a14). */
-int skinrt_get_aabbs(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
-/* Joint palette [I][J][24] f32: 3 rows x 4 of the joint matrix (row r = m[r][0..3] incl.
- * translation), then 3 rows x 4 of the normal matrix (4th of each row = 0).
- * Same numbers as SkinMatrix (uniform/skin.rs:12-17), transposed to rows; see
- * skinrt_export_skin_uniform for the reference byte layout. */
-int skinrt_get_palette(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
-/* Node world matrices [I][N][12] f32, 3 rows x 4 (the Mat4's first three rows). */
-int skinrt_get_world(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
-/* Selected keyframe per (instance, channel of the instance's clip): [I][Cmax] u32, Cmax =
- * largest clip channel count; entries past the clip's channel count are UINT32_MAX. */
-int skinrt_get_keyframe_index(skinrt_crowd* crowd, uint32_t** out_dev, uint64_t* out_count);
-
-/* Copy `bytes` from a device pointer returned above to host memory (synchronises the ctx). */
-int skinrt_download(skinrt_ctx* ctx, const void* dev_src, void* host_dst, uint64_t bytes);
-
-/* ---- reference-layout exports (host destinations) ---------------------------------------- */
-/* One instance's palette as the reference uploads it: 128 x SkinMatrix (112 B each: mat4
- * column-major, then 3 x vec4 normal columns padded with 0), entries >= J zero
- * (uniform/skin.rs:41-50; shader.wgsl:70-77).  Requires J <= 128. dst: 14336 bytes. */
-int skinrt_export_skin_uniform(skinrt_crowd* crowd, uint32_t instance, void* dst);
-/* One instance's vertices in ColorSkinVertex (68 B) or TextureSkinVertex (60 B) layout
- * (buffer/vertex.rs:60-102): position/normal/tangent = skinned outputs, joint_index =
- * 0,0,0,0 and joint_weight = 1,0,0,0 are NOT emitted — the rig's set-0 indices/weights are
- * passed through so the reference shader can re-skin or ignore them; color (4 f32) or
- * tex_coords (2 f32) are copied from `attr` ([V][4] or [V][2], NULL = zeros). dst: V*stride bytes. */
-int skinrt_export_interleaved(skinrt_crowd* crowd, uint32_t instance, uint32_t layout,
-                              const float* attr, void* dst);
-
 /* ---- rig introspection (what upload compiled; used by tests and the bench roofline) ------- */
 typedef struct skinrt_rig_info {
     uint32_t node_count, joint_count, vertex_count, set_count, target_count, clip_count;
@@ -256,7 +179,96 @@ typedef struct skinrt_rig_info {
     uint64_t morph_entries;        /* nonzero (vertex,target) pairs kept after compaction */
     uint64_t device_bytes;         /* bytes of device memory the rig occupies */
 } skinrt_rig_info;
-int skinrt_get_rig_info(skinrt_rig* rig, skinrt_rig_info* out_info);
+
+/* ---- lifecycle --------------------------------------------------------------------- */
+
+/* Library/ABI version (SKINRT_ABI_VERSION). No reference counterpart. */
+SKINRT_API int skinrt_abi_version(void);
+
+/* Text of the last error raised on the calling thread ("" if none).
+ * Stands in for GltfLoaderError's Display impl (loader/gltf/mod.rs:78-173). */
+SKINRT_API const char* skinrt_last_error(void);
+
+/* Create a context on config->device with its own HIP stream.
+ * Replaces wgpu device/queue acquisition for this path (renderer/src/state.rs:94-127). */
+SKINRT_API int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx);
+SKINRT_API int skinrt_destroy_ctx(skinrt_ctx* ctx);
+
+/* Validate, compile (vertex tiles, tile-local joint lists, per-vertex morph lists,
+ * depth levels) and upload a rig.  Replaces VertexBuffer::new (renderer/buffer/vertex.rs:110-121)
+ * and the one-time walk of (Vec<SceneAsset>, Vec<AnimationAsset>) (loader/gltf/mod.rs:199). */
+SKINRT_API int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig** out_rig);
+/* Validate and compile a rig on the host only (no device needed); fills out_info (may be NULL).
+ * Same error codes as skinrt_upload_rig.  config may be NULL (defaults). */
+SKINRT_API int skinrt_validate_rig(const skinrt_config* config, const skinrt_rig_desc* desc, skinrt_rig_info* out_info);
+SKINRT_API int skinrt_destroy_rig(skinrt_rig* rig);
+/* What skinrt_upload_rig compiled for this rig. No reference counterpart. */
+SKINRT_API int skinrt_get_rig_info(skinrt_rig* rig, skinrt_rig_info* out_info);
+
+/* Allocate per-instance state and output buffers for `instances` copies of `rig`.
+ * Replaces one SkinUniformBuffer::new per entity (renderer/uniform/skin.rs:39-57). */
+SKINRT_API int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, skinrt_crowd** out_crowd);
+SKINRT_API int skinrt_destroy_crowd(skinrt_crowd* crowd);
+
+/* ---- per-frame inputs ----------------------------------------------------------------- */
+
+/* Per-instance animation clock tau[I] (seconds, already wrapped by the caller) and clip
+ * index clip_id[I] (NULL = clip 0; UINT32_MAX = rest pose).  Keyframe search rule: SURVEY.md §8a a4. */
+SKINRT_API int skinrt_set_clocks(skinrt_crowd* crowd, const float* tau, const uint32_t* clip_id);
+/* Per-instance morph weights w[I][M] (NodeAsset.weights override, node.rs:98); NULL restores
+ * the rig's default weights for every instance. */
+SKINRT_API int skinrt_set_morph_weights(skinrt_crowd* crowd, const float* weights);
+/* Per-instance root placement m[I][16] (pre-multiplies every scene root); NULL = none.
+ * Replaces InstanceUniformBuffer.transform for crowd placement (renderer/uniform/transform.rs:17-20). */
+SKINRT_API int skinrt_set_root_transforms(skinrt_crowd* crowd, const float* matrices);
+
+/* ---- evaluation ------------------------------------------------------------------------ */
+
+/* Enqueue the selected stages on the ctx stream (asynchronous).  This is the body the
+ * reference leaves empty at Entity::render (renderer/src/client/entity/mod.rs:34). */
+SKINRT_API int skinrt_evaluate(skinrt_crowd* crowd, uint32_t stages_mask);
+/* Block until everything enqueued on the ctx stream has finished. */
+SKINRT_API int skinrt_synchronize(skinrt_ctx* ctx);
+/* Device time of the last evaluate's kernels in ms (HIP events on the ctx stream):
+ * ms[0]=pose, ms[1]=skin+morph, ms[2]=aabb reduce, ms[3]=total span.  Synchronises. */
+SKINRT_API int skinrt_last_stage_ms(skinrt_crowd* crowd, float ms[4]);
+/* The ctx's hipStream_t, for callers that order their own work against it. */
+SKINRT_API int skinrt_get_stream(skinrt_ctx* ctx, void** out_stream);
+
+/* ---- outputs (device pointers) --------------------------------------------------------- */
+/* Skinned world-space positions / normals / tangents, each [I][V][3] f32
+ * (shader.wgsl:159-163,:223-226: skin_matrix * vec4(position,1), normal_matrix * normal/tangent). */
+SKINRT_API int skinrt_get_positions(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+SKINRT_API int skinrt_get_normals(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+SKINRT_API int skinrt_get_tangents(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+/* Per-instance bounds [I][2][3] f32 (min xyz, max xyz).  No reference counterpart (a14). */
+SKINRT_API int skinrt_get_aabbs(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+/* Joint palette [I][J][24] f32: 3 rows x 4 of the joint matrix (row r = m[r][0..3] incl.
+ * translation), then 3 rows x 4 of the normal matrix (4th of each row = 0).
+ * Same numbers as SkinMatrix (uniform/skin.rs:12-17), transposed to rows; see
+ * skinrt_export_skin_uniform for the reference byte layout. */
+SKINRT_API int skinrt_get_palette(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+/* Node world matrices [I][N][12] f32, 3 rows x 4 (the Mat4's first three rows). */
+SKINRT_API int skinrt_get_world(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
+/* Selected keyframe per (instance, channel of the instance's clip): [I][Cmax] u32, Cmax =
+ * largest clip channel count; entries past the clip's channel count are UINT32_MAX. */
+SKINRT_API int skinrt_get_keyframe_index(skinrt_crowd* crowd, uint32_t** out_dev, uint64_t* out_count);
+
+/* Copy `bytes` from a device pointer returned above to host memory (synchronises the ctx). */
+SKINRT_API int skinrt_download(skinrt_ctx* ctx, const void* dev_src, void* host_dst, uint64_t bytes);
+
+/* ---- reference-layout exports (host destinations) ---------------------------------------- */
+/* One instance's palette as the reference uploads it: 128 x SkinMatrix (112 B each: mat4
+ * column-major, then 3 x vec4 normal columns padded with 0), entries >= J zero
+ * (uniform/skin.rs:41-50; shader.wgsl:70-77).  Requires J <= 128. dst: 14336 bytes. */
+SKINRT_API int skinrt_export_skin_uniform(skinrt_crowd* crowd, uint32_t instance, void* dst);
+/* One instance's vertices in ColorSkinVertex (68 B) or TextureSkinVertex (60 B) layout
+ * (buffer/vertex.rs:60-102): position/normal/tangent = skinned outputs; joint_index /
+ * joint_weight = the rig's set-0 indices/weights passed through unchanged; color (4 f32) or
+ * tex_coords (2 f32) are copied from `attr` ([V][4] or [V][2], NULL = zeros). dst: V*stride bytes. */
+SKINRT_API int skinrt_export_interleaved(skinrt_crowd* crowd, uint32_t instance, uint32_t layout,
+                              const float* attr, void* dst);
+
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,9 @@ class Config(C.Structure):
         ("cubic_quirk", C.c_uint32),
         ("normalize_outputs", C.c_uint32),
         ("reference_limits", C.c_uint32),
-        ("reserved", C.c_uint32 * 3),
+        ("exact_arithmetic", C.c_uint32),
+        ("pose_path", C.c_uint32),
+        ("reserved", C.c_uint32 * 1),
     ]
 
 

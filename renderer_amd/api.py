@@ -1,0 +1,275 @@
+"""Python host side over the C ABI (include/skinrt.h), via ctypes.
+
+There is no Rust toolchain in this image, so the caller above the boundary is Python here;
+the Rust-side binding a maintainer would add is in INTEGRATION.md.  These classes mirror the
+reference's objects on this path: `Rig` ~ the uploaded (Vec<SceneAsset>, Vec<AnimationAsset>)
+(renderer-asset/src/loader/gltf/mod.rs:199), `Crowd.evaluate` ~ the body of `Entity::render`
+(renderer/src/client/entity/mod.rs:34), `Crowd.skin_uniform` ~ `SkinUniformBuffer::update`
+(renderer/src/renderer/uniform/skin.rs:59-71).
+
+The HIP library is mandatory: there is no CPU fallback.  If libskinrt.so is missing or no GPU is
+present, construction fails loudly (SkinrtError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import abi
+from .abi import Config, RigData, RigDesc, RigInfo
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libskinrt.so")
+_lib = None
+
+# every symbol include/skinrt.h declares
+EXPORTS = [
+    "skinrt_abi_version", "skinrt_last_error", "skinrt_init", "skinrt_destroy_ctx", "skinrt_upload_rig",
+    "skinrt_validate_rig", "skinrt_destroy_rig", "skinrt_get_rig_info", "skinrt_create_crowd",
+    "skinrt_destroy_crowd", "skinrt_set_clocks", "skinrt_set_morph_weights", "skinrt_set_root_transforms",
+    "skinrt_evaluate", "skinrt_synchronize", "skinrt_last_stage_ms", "skinrt_get_stream",
+    "skinrt_get_positions", "skinrt_get_normals", "skinrt_get_tangents", "skinrt_get_aabbs",
+    "skinrt_get_palette", "skinrt_get_world", "skinrt_get_keyframe_index", "skinrt_download",
+    "skinrt_export_skin_uniform", "skinrt_export_interleaved",
+]
+
+
+class SkinrtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"skinrt error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """Load libskinrt.so (built in-tree by __graft_entry__.build()).  No fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise SkinrtError(abi.E_DEVICE, f"{_LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(_LIB_PATH)
+    vp = C.c_void_p
+    lib.skinrt_abi_version.restype = C.c_int
+    lib.skinrt_last_error.restype = C.c_char_p
+    sigs = {
+        "skinrt_init": [C.POINTER(Config), C.POINTER(vp)],
+        "skinrt_destroy_ctx": [vp],
+        "skinrt_upload_rig": [vp, C.POINTER(RigDesc), C.POINTER(vp)],
+        "skinrt_validate_rig": [C.POINTER(Config), C.POINTER(RigDesc), C.POINTER(RigInfo)],
+        "skinrt_destroy_rig": [vp],
+        "skinrt_get_rig_info": [vp, C.POINTER(RigInfo)],
+        "skinrt_create_crowd": [vp, vp, C.c_uint32, C.POINTER(vp)],
+        "skinrt_destroy_crowd": [vp],
+        "skinrt_set_clocks": [vp, vp, vp],
+        "skinrt_set_morph_weights": [vp, vp],
+        "skinrt_set_root_transforms": [vp, vp],
+        "skinrt_evaluate": [vp, C.c_uint32],
+        "skinrt_synchronize": [vp],
+        "skinrt_last_stage_ms": [vp, C.POINTER(C.c_float * 4)],
+        "skinrt_get_stream": [vp, C.POINTER(vp)],
+        "skinrt_download": [vp, vp, vp, C.c_uint64],
+        "skinrt_export_skin_uniform": [vp, C.c_uint32, vp],
+        "skinrt_export_interleaved": [vp, C.c_uint32, C.c_uint32, vp, vp],
+    }
+    for g in ("positions", "normals", "tangents", "aabbs", "palette", "world", "keyframe_index"):
+        sigs[f"skinrt_get_{g}"] = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise SkinrtError(rc, load_library().skinrt_last_error().decode("utf-8", "replace"))
+
+
+def make_config(device: int = 0, cubic_quirk: int = 1, normalize_outputs: int = 0, reference_limits: int = 0,
+                exact_arithmetic: int = 0, pose_path: int = 0) -> Config:
+    cfg = Config()
+    cfg.struct_size = C.sizeof(Config)
+    cfg.device = device
+    cfg.cubic_quirk = cubic_quirk
+    cfg.normalize_outputs = normalize_outputs
+    cfg.reference_limits = reference_limits
+    cfg.exact_arithmetic = exact_arithmetic
+    cfg.pose_path = pose_path
+    return cfg
+
+
+def validate_rig(rig: RigData, config: Optional[Config] = None) -> RigInfo:
+    """Host-only validation + compilation (no GPU needed)."""
+    lib = load_library()
+    info = RigInfo()
+    desc = rig.to_desc()
+    _check(lib.skinrt_validate_rig(C.byref(config) if config is not None else None, C.byref(desc), C.byref(info)))
+    return info
+
+
+class Context:
+    def __init__(self, device: int = 0, **cfg):
+        self.lib = load_library()
+        self.config = make_config(device=device, **cfg)
+        self.handle = C.c_void_p()
+        _check(self.lib.skinrt_init(C.byref(self.config), C.byref(self.handle)))
+
+    def synchronize(self):
+        _check(self.lib.skinrt_synchronize(self.handle))
+
+    @property
+    def stream(self) -> int:
+        s = C.c_void_p()
+        _check(self.lib.skinrt_get_stream(self.handle, C.byref(s)))
+        return s.value or 0
+
+    def download(self, dev_ptr: int, count: int, dtype) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        _check(self.lib.skinrt_download(self.handle, C.c_void_p(dev_ptr), out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.lib.skinrt_destroy_ctx(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Rig:
+    def __init__(self, ctx: Context, data: RigData):
+        self.ctx = ctx
+        self.data = data
+        self.handle = C.c_void_p()
+        desc = data.to_desc()
+        _check(ctx.lib.skinrt_upload_rig(ctx.handle, C.byref(desc), C.byref(self.handle)))
+
+    @property
+    def info(self) -> RigInfo:
+        info = RigInfo()
+        _check(self.ctx.lib.skinrt_get_rig_info(self.handle, C.byref(info)))
+        return info
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.skinrt_destroy_rig(self.handle)
+            self.handle = C.c_void_p()
+
+
+class Crowd:
+    def __init__(self, ctx: Context, rig: Rig, instances: int):
+        self.ctx, self.rig, self.instances = ctx, rig, int(instances)
+        self.handle = C.c_void_p()
+        _check(ctx.lib.skinrt_create_crowd(ctx.handle, rig.handle, self.instances, C.byref(self.handle)))
+
+    # inputs ------------------------------------------------------------------------------
+    def set_clocks(self, tau, clip_id=None):
+        tau = np.ascontiguousarray(tau, dtype=np.float32)
+        assert tau.shape == (self.instances,)
+        cp = None
+        if clip_id is not None:
+            clip_id = np.ascontiguousarray(clip_id, dtype=np.uint32)
+            assert clip_id.shape == (self.instances,)
+            cp = clip_id.ctypes.data_as(C.c_void_p)
+        _check(self.ctx.lib.skinrt_set_clocks(self.handle, tau.ctypes.data_as(C.c_void_p), cp))
+
+    def set_morph_weights(self, weights):
+        wp = None
+        if weights is not None:
+            weights = np.ascontiguousarray(weights, dtype=np.float32)
+            assert weights.shape == (self.instances, self.rig.data.target_count)
+            wp = weights.ctypes.data_as(C.c_void_p)
+        _check(self.ctx.lib.skinrt_set_morph_weights(self.handle, wp))
+
+    def set_root_transforms(self, matrices):
+        mp = None
+        if matrices is not None:
+            matrices = np.ascontiguousarray(matrices, dtype=np.float32)
+            assert matrices.shape == (self.instances, 16)
+            mp = matrices.ctypes.data_as(C.c_void_p)
+        _check(self.ctx.lib.skinrt_set_root_transforms(self.handle, mp))
+
+    # evaluation ----------------------------------------------------------------------------
+    def evaluate(self, stages: int = abi.STAGE_ALL, sync: bool = False):
+        _check(self.ctx.lib.skinrt_evaluate(self.handle, stages))
+        if sync:
+            self.ctx.synchronize()
+
+    def stage_ms(self) -> Tuple[float, float, float, float]:
+        ms = (C.c_float * 4)()
+        _check(self.ctx.lib.skinrt_last_stage_ms(self.handle, C.byref(ms)))
+        return tuple(float(x) for x in ms)
+
+    # outputs ---------------------------------------------------------------------------------
+    def _dev(self, name: str) -> Tuple[int, int]:
+        p = C.c_void_p()
+        n = C.c_uint64()
+        _check(getattr(self.ctx.lib, f"skinrt_get_{name}")(self.handle, C.byref(p), C.byref(n)))
+        return (p.value or 0), int(n.value)
+
+    def device_pointer(self, name: str) -> Tuple[int, int]:
+        """(device address, element count) of 'positions' | 'normals' | 'tangents' | 'aabbs' |
+        'palette' | 'world' | 'keyframe_index'."""
+        return self._dev(name)
+
+    def _fetch(self, name, dtype, shape, first=0, count=None):
+        ptr, n = self._dev(name)
+        per = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        count = shape[0] - first if count is None else count
+        item = np.dtype(dtype).itemsize
+        out = self.ctx.download(ptr + first * per * item, count * per, dtype)
+        return out.reshape((count,) + tuple(shape[1:]))
+
+    def positions(self, first=0, count=None):
+        return self._fetch("positions", np.float32, (self.instances, self.rig.data.vertex_count, 3), first, count)
+
+    def normals(self, first=0, count=None):
+        return self._fetch("normals", np.float32, (self.instances, self.rig.data.vertex_count, 3), first, count)
+
+    def tangents(self, first=0, count=None):
+        return self._fetch("tangents", np.float32, (self.instances, self.rig.data.vertex_count, 3), first, count)
+
+    def aabbs(self, first=0, count=None):
+        return self._fetch("aabbs", np.float32, (self.instances, 2, 3), first, count)
+
+    def palette(self, first=0, count=None):
+        return self._fetch("palette", np.float32, (self.instances, self.rig.data.joint_count, 24), first, count)
+
+    def world(self, first=0, count=None):
+        return self._fetch("world", np.float32, (self.instances, self.rig.data.node_count, 12), first, count)
+
+    def keyframe_index(self, first=0, count=None):
+        return self._fetch("keyframe_index", np.uint32, (self.instances, self.rig.data.max_channels), first, count)
+
+    def skin_uniform(self, instance: int) -> np.ndarray:
+        """128 x SkinMatrix (28 f32 each) exactly as the reference uploads it (uniform/skin.rs:41-50)."""
+        out = np.empty((128, 28), dtype=np.float32)
+        _check(self.ctx.lib.skinrt_export_skin_uniform(self.handle, instance, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def interleaved(self, instance: int, layout: int, attr=None) -> np.ndarray:
+        stride = 68 if layout == abi.LAYOUT_COLOR_SKIN else 60
+        out = np.empty(self.rig.data.vertex_count * stride, dtype=np.uint8)
+        ap = None
+        if attr is not None:
+            attr = np.ascontiguousarray(attr, dtype=np.float32)
+            ap = attr.ctypes.data_as(C.c_void_p)
+        _check(self.ctx.lib.skinrt_export_interleaved(self.handle, instance, layout, ap, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.skinrt_destroy_crowd(self.handle)
+            self.handle = C.c_void_p()

@@ -1,0 +1,462 @@
+// api.hip — the C ABI of include/skinrt.h over the HIP kernels.  No torch types, no
+// exceptions across the boundary; every HIP failure becomes SKINRT_E_DEVICE with text.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "device_types.hpp"
+
+using namespace skinrt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? SKINRT_E_NOMEM : SKINRT_E_DEVICE,         \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t alloc(size_t n) {
+        bytes = n;
+        if (n == 0) { p = nullptr; return hipSuccess; }
+        return hipMalloc(&p, n);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct skinrt_ctx {
+    skinrt_config cfg{};
+    hipStream_t stream = nullptr;
+};
+
+struct skinrt_rig {
+    skinrt_ctx* ctx = nullptr;
+    CompiledRig host;          // tables kept on the host for exports / info (vectors stay small vs HBM)
+    RigDev dev{};
+    std::vector<DevBuf> bufs;
+    uint64_t device_bytes = 0;
+    DevBuf default_mw;
+};
+
+struct skinrt_crowd {
+    skinrt_ctx* ctx = nullptr;
+    skinrt_rig* rig = nullptr;
+    uint32_t I = 0;
+    DevBuf tau, clip, mw, root, world, palette, keyidx, pos, nrm, tan, aabb_part, aabb;
+    bool has_root = false;
+    SkinPlan plan{};
+    PosePath pose_path = kPoseWave;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t last_mask = 0;
+    CrowdDev dev() const {
+        CrowdDev c{};
+        c.I = I;
+        c.tau = tau.as<float>(); c.clip = clip.as<uint32_t>(); c.mw = mw.as<float>();
+        c.root = has_root ? root.as<float>() : nullptr;
+        c.world = world.as<float>(); c.palette = palette.as<float>(); c.keyidx = keyidx.as<uint32_t>();
+        c.pos = pos.as<float>(); c.nrm = nrm.as<float>(); c.tan = tan.as<float>();
+        c.aabb_part = aabb_part.as<float>(); c.aabb = aabb.as<float>();
+        return c;
+    }
+};
+
+namespace {
+
+template <class T>
+int upload(skinrt_rig* r, const std::vector<T>& v, const T** out) {
+    DevBuf b;
+    // never hand the kernels a null table: keep at least one element
+    const size_t n = std::max<size_t>(v.size(), 1) * sizeof(T);
+    HIP_TRY(b.alloc(n));
+    r->bufs.push_back(b);
+    r->device_bytes += n;
+    if (!v.empty()) HIP_TRY(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(b.p, 0, n));
+    *out = b.as<T>();
+    return SKINRT_OK;
+}
+
+uint32_t ceil_log2(uint32_t x) {
+    uint32_t s = 0;
+    while ((1u << s) < x) ++s;
+    return s;
+}
+
+SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
+    SkinPlan p{};
+    p.jt_shift = ceil_log2(std::max<uint32_t>(1, r.max_tile_joints));
+    const uint32_t JTP = 1u << p.jt_shift;
+    const uint32_t per_inst = JTP * 96 + r.M * 4 + 16 * 6 * 4;
+    const uint32_t budget = 40 * 1024;
+    p.batch = std::min<uint32_t>(16, std::max<uint32_t>(1, budget / per_inst));
+    p.lds_bytes = p.batch * per_inst;
+    // enough blocks to fill 256 CUs several times over, but ranges long enough to amortise the
+    // per-block vertex load
+    const uint64_t want_blocks = 4096;
+    uint64_t range = ((uint64_t)I * std::max<uint32_t>(1, r.T) + want_blocks - 1) / want_blocks;
+    range = std::min<uint64_t>(std::max<uint64_t>(range, p.batch), 256);
+    range = (range + p.batch - 1) / p.batch * p.batch;
+    p.range = (uint32_t)range;
+    p.ranges = I ? (I + p.range - 1) / p.range : 0;
+    p.exact = cfg.exact_arithmetic ? 1 : 0;
+    p.normalize = cfg.normalize_outputs ? 1 : 0;
+    p.aabb = 0;
+    return p;
+}
+
+bool affine_last_row(const float* m) { return m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f; }
+
+int check_crowd(skinrt_crowd* c) {
+    if (!c || !c->ctx || !c->rig) return fail(SKINRT_E_INVALID, "crowd handle is NULL");
+    return SKINRT_OK;
+}
+
+int get_buf(skinrt_crowd* c, const DevBuf& b, size_t elem, void** out_dev, uint64_t* out_count) {
+    if (int rc = check_crowd(c)) return rc;
+    if (!out_dev) return fail(SKINRT_E_INVALID, "out_dev is NULL");
+    *out_dev = b.p;
+    if (out_count) *out_count = b.bytes / elem;
+    return SKINRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int skinrt_abi_version(void) { return SKINRT_ABI_VERSION; }
+
+const char* skinrt_last_error(void) { return g_err.c_str(); }
+
+int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx) {
+    if (!config || !out_ctx) return fail(SKINRT_E_INVALID, "skinrt_init: NULL argument");
+    if (config->struct_size != sizeof(skinrt_config)) return fail(SKINRT_E_INVALID, "skinrt_config.struct_size mismatch");
+    if (config->pose_path > 2) return fail(SKINRT_E_INVALID, "skinrt_config.pose_path must be 0, 1 or 2");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (config->device < 0 || config->device >= count) return fail(SKINRT_E_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(config->device));
+    skinrt_ctx* ctx = new (std::nothrow) skinrt_ctx;
+    if (!ctx) return fail(SKINRT_E_NOMEM, "out of host memory");
+    ctx->cfg = *config;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(SKINRT_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out_ctx = ctx;
+    return SKINRT_OK;
+}
+
+int skinrt_destroy_ctx(skinrt_ctx* ctx) {
+    if (!ctx) return SKINRT_OK;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+    return SKINRT_OK;
+}
+
+int skinrt_validate_rig(const skinrt_config* config, const skinrt_rig_desc* desc, skinrt_rig_info* out_info) {
+    CompiledRig r;
+    std::string err;
+    const int rc = compile_rig(desc, config, r, err);
+    if (rc != SKINRT_OK) return fail(rc, err);
+    if (out_info) fill_rig_info(r, 0, out_info);
+    return SKINRT_OK;
+}
+
+int skinrt_destroy_rig(skinrt_rig* rig) {
+    if (!rig) return SKINRT_OK;
+    if (rig->ctx) (void)hipSetDevice(rig->ctx->cfg.device);
+    for (auto& b : rig->bufs) b.release();
+    delete rig;
+    return SKINRT_OK;
+}
+
+int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig** out_rig) {
+    if (!ctx || !out_rig) return fail(SKINRT_E_INVALID, "skinrt_upload_rig: NULL argument");
+    skinrt_rig* r = new (std::nothrow) skinrt_rig;
+    if (!r) return fail(SKINRT_E_NOMEM, "out of host memory");
+    r->ctx = ctx;
+    std::string err;
+    int rc = compile_rig(desc, &ctx->cfg, r->host, err);
+    if (rc != SKINRT_OK) {
+        delete r;
+        return fail(rc, err);
+    }
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    const CompiledRig& h = r->host;
+    RigDev& d = r->dev;
+    d.N = h.N; d.J = h.J; d.V = h.V; d.K = h.K; d.M = h.M; d.clips = h.clips; d.Cmax = h.Cmax;
+    d.levels = h.levels; d.T = h.T;
+    const float* defw = nullptr;
+#define UP(field) if ((rc = upload(r, h.field, &d.field)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
+    UP(parent) UP(rest_trs) UP(rest_mat) UP(node_matrix) UP(level_start) UP(level_nodes) UP(node_chan)
+    UP(chans) UP(clip_chan_count) UP(times) UP(values) UP(joint_node) UP(ibm) UP(base) UP(wts) UP(lidx)
+    UP(tile_joint_start) UP(tile_joints) UP(tile_lds) UP(mptr) UP(mtgt) UP(mdelta)
+#undef UP
+    if ((rc = upload(r, h.default_weights, &defw)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
+    r->default_mw = r->bufs.back();
+    *out_rig = r;
+    return SKINRT_OK;
+}
+
+int skinrt_get_rig_info(skinrt_rig* rig, skinrt_rig_info* out_info) {
+    if (!rig || !out_info) return fail(SKINRT_E_INVALID, "skinrt_get_rig_info: NULL argument");
+    fill_rig_info(rig->host, rig->device_bytes, out_info);
+    return SKINRT_OK;
+}
+
+int skinrt_destroy_crowd(skinrt_crowd* c) {
+    if (!c) return SKINRT_OK;
+    if (c->ctx) {
+        (void)hipSetDevice(c->ctx->cfg.device);
+        (void)hipStreamSynchronize(c->ctx->stream);
+    }
+    for (DevBuf* b : {&c->tau, &c->clip, &c->mw, &c->root, &c->world, &c->palette, &c->keyidx, &c->pos, &c->nrm,
+                      &c->tan, &c->aabb_part, &c->aabb})
+        b->release();
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete c;
+    return SKINRT_OK;
+}
+
+int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, skinrt_crowd** out_crowd) {
+    if (!ctx || !rig || !out_crowd) return fail(SKINRT_E_INVALID, "skinrt_create_crowd: NULL argument");
+    if (rig->ctx != ctx) return fail(SKINRT_E_INVALID, "rig belongs to another ctx");
+    if (instances == 0) return fail(SKINRT_E_INVALID, "a crowd needs at least one instance");
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    skinrt_crowd* c = new (std::nothrow) skinrt_crowd;
+    if (!c) return fail(SKINRT_E_NOMEM, "out of host memory");
+    c->ctx = ctx; c->rig = rig; c->I = instances;
+    const CompiledRig& h = rig->host;
+    const size_t I = instances;
+    struct { DevBuf* b; size_t n; } plan[] = {
+        {&c->tau, I * 4}, {&c->clip, I * 4}, {&c->mw, I * h.M * 4}, {&c->root, I * 48},
+        {&c->world, I * h.N * 48}, {&c->palette, I * h.J * 96}, {&c->keyidx, I * h.Cmax * 4},
+        {&c->pos, I * h.V * 12}, {&c->nrm, I * h.V * 12}, {&c->tan, I * h.V * 12},
+        {&c->aabb_part, I * h.T * 24}, {&c->aabb, I * 24},
+    };
+    for (auto& it : plan) {
+        hipError_t e = it.b->alloc(it.n);
+        if (e != hipSuccess) {
+            skinrt_destroy_crowd(c);
+            return fail(SKINRT_E_NOMEM, std::string("hipMalloc of crowd buffers: ") + hipGetErrorString(e));
+        }
+    }
+    for (auto& e : c->ev) {
+        if (hipEventCreate(&e) != hipSuccess) {
+            skinrt_destroy_crowd(c);
+            return fail(SKINRT_E_DEVICE, "hipEventCreate failed");
+        }
+    }
+    // defaults: clock 0, clip 0, rig default morph weights, no root transform
+    hipError_t e = hipMemsetAsync(c->tau.p, 0, c->tau.bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->clip.p, 0, c->clip.bytes, ctx->stream);
+    if (e == hipSuccess && h.M) e = launch_fill_morph_weights(c->mw.as<float>(), rig->default_mw.as<float>(), instances, h.M, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        skinrt_destroy_crowd(c);
+        return fail(SKINRT_E_DEVICE, std::string("crowd initialisation: ") + hipGetErrorString(e));
+    }
+    c->plan = plan_skin(h, instances, ctx->cfg);
+    const bool fits = (size_t)h.N * 48 <= 48 * 1024;
+    if (ctx->cfg.pose_path == 1) {
+        if (!fits) { skinrt_destroy_crowd(c); return fail(SKINRT_E_INVALID, "pose_path=1 (wavefront) needs node_count <= 1024"); }
+        c->pose_path = kPoseWave;
+    } else if (ctx->cfg.pose_path == 2) c->pose_path = kPoseSplit;
+    else c->pose_path = (fits && h.levels <= 256) ? kPoseWave : kPoseSplit;
+    *out_crowd = c;
+    return SKINRT_OK;
+}
+
+int skinrt_set_clocks(skinrt_crowd* c, const float* tau, const uint32_t* clip_id) {
+    if (int rc = check_crowd(c)) return rc;
+    if (!tau) return fail(SKINRT_E_INVALID, "tau is NULL");
+    HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+    if (clip_id)
+        for (uint32_t i = 0; i < c->I; ++i)
+            if (clip_id[i] != UINT32_MAX && clip_id[i] >= c->rig->host.clips)
+                return fail(SKINRT_E_RANGE, "clip_id out of range");
+    HIP_TRY(hipMemcpyAsync(c->tau.p, tau, c->tau.bytes, hipMemcpyHostToDevice, c->ctx->stream));
+    if (clip_id) HIP_TRY(hipMemcpyAsync(c->clip.p, clip_id, c->clip.bytes, hipMemcpyHostToDevice, c->ctx->stream));
+    else HIP_TRY(hipMemsetAsync(c->clip.p, 0, c->clip.bytes, c->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));  // host buffers are borrowed for the call only
+    return SKINRT_OK;
+}
+
+int skinrt_set_morph_weights(skinrt_crowd* c, const float* weights) {
+    if (int rc = check_crowd(c)) return rc;
+    const uint32_t M = c->rig->host.M;
+    if (M == 0) return SKINRT_OK;
+    HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+    if (weights) HIP_TRY(hipMemcpyAsync(c->mw.p, weights, c->mw.bytes, hipMemcpyHostToDevice, c->ctx->stream));
+    else HIP_TRY(launch_fill_morph_weights(c->mw.as<float>(), c->rig->default_mw.as<float>(), c->I, M, c->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    return SKINRT_OK;
+}
+
+int skinrt_set_root_transforms(skinrt_crowd* c, const float* matrices) {
+    if (int rc = check_crowd(c)) return rc;
+    if (!matrices) { c->has_root = false; return SKINRT_OK; }
+    std::vector<float> rows;
+    try { rows.resize((size_t)c->I * 12); } catch (const std::bad_alloc&) { return fail(SKINRT_E_NOMEM, "out of host memory"); }
+    for (uint32_t i = 0; i < c->I; ++i) {
+        const float* m = matrices + (size_t)i * 16;
+        if (!affine_last_row(m)) return fail(SKINRT_E_NONAFFINE, "root matrix last row is not 0,0,0,1");
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 4; ++k) rows[(size_t)i * 12 + r * 4 + k] = m[k * 4 + r];
+    }
+    HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+    HIP_TRY(hipMemcpy(c->root.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+    c->has_root = true;
+    return SKINRT_OK;
+}
+
+int skinrt_evaluate(skinrt_crowd* c, uint32_t mask) {
+    if (int rc = check_crowd(c)) return rc;
+    if (mask == 0 || (mask & ~SKINRT_STAGE_ALL)) return fail(SKINRT_E_INVALID, "bad stages_mask");
+    if ((mask & SKINRT_STAGE_AABB) && !(mask & SKINRT_STAGE_SKIN)) return fail(SKINRT_E_INVALID, "STAGE_AABB needs STAGE_SKIN");
+    HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+    hipStream_t s = c->ctx->stream;
+    const RigDev& rig = c->rig->dev;
+    const CrowdDev cr = c->dev();
+    HIP_TRY(hipEventRecord(c->ev[0], s));
+    if (mask & SKINRT_STAGE_POSE) HIP_TRY(launch_pose(rig, cr, c->ctx->cfg.cubic_quirk ? 1u : 0u, c->pose_path, s));
+    HIP_TRY(hipEventRecord(c->ev[1], s));
+    if (mask & SKINRT_STAGE_SKIN) {
+        SkinPlan p = c->plan;
+        p.aabb = (mask & SKINRT_STAGE_AABB) ? 1 : 0;
+        HIP_TRY(launch_skin(rig, cr, p, s));
+    }
+    HIP_TRY(hipEventRecord(c->ev[2], s));
+    if (mask & SKINRT_STAGE_AABB) HIP_TRY(launch_aabb_reduce(rig, cr, s));
+    HIP_TRY(hipEventRecord(c->ev[3], s));
+    c->last_mask = mask;
+    return SKINRT_OK;
+}
+
+int skinrt_synchronize(skinrt_ctx* ctx) {
+    if (!ctx) return fail(SKINRT_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SKINRT_OK;
+}
+
+int skinrt_last_stage_ms(skinrt_crowd* c, float ms[4]) {
+    if (int rc = check_crowd(c)) return rc;
+    if (!ms) return fail(SKINRT_E_INVALID, "ms is NULL");
+    if (!c->last_mask) return fail(SKINRT_E_INVALID, "no evaluate has been enqueued on this crowd");
+    HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+    HIP_TRY(hipEventSynchronize(c->ev[3]));
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], c->ev[k], c->ev[k + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms[3], c->ev[0], c->ev[3]));
+    return SKINRT_OK;
+}
+
+int skinrt_get_stream(skinrt_ctx* ctx, void** out_stream) {
+    if (!ctx || !out_stream) return fail(SKINRT_E_INVALID, "skinrt_get_stream: NULL argument");
+    *out_stream = ctx->stream;
+    return SKINRT_OK;
+}
+
+int skinrt_get_positions(skinrt_crowd* c, float** o, uint64_t* n) { return c ? get_buf(c, c->pos, 4, (void**)o, n) : check_crowd(c); }
+int skinrt_get_normals(skinrt_crowd* c, float** o, uint64_t* n) { return c ? get_buf(c, c->nrm, 4, (void**)o, n) : check_crowd(c); }
+int skinrt_get_tangents(skinrt_crowd* c, float** o, uint64_t* n) { return c ? get_buf(c, c->tan, 4, (void**)o, n) : check_crowd(c); }
+int skinrt_get_aabbs(skinrt_crowd* c, float** o, uint64_t* n) { return c ? get_buf(c, c->aabb, 4, (void**)o, n) : check_crowd(c); }
+int skinrt_get_palette(skinrt_crowd* c, float** o, uint64_t* n) { return c ? get_buf(c, c->palette, 4, (void**)o, n) : check_crowd(c); }
+int skinrt_get_world(skinrt_crowd* c, float** o, uint64_t* n) { return c ? get_buf(c, c->world, 4, (void**)o, n) : check_crowd(c); }
+int skinrt_get_keyframe_index(skinrt_crowd* c, uint32_t** o, uint64_t* n) { return c ? get_buf(c, c->keyidx, 4, (void**)o, n) : check_crowd(c); }
+
+int skinrt_download(skinrt_ctx* ctx, const void* dev_src, void* host_dst, uint64_t bytes) {
+    if (!ctx) return fail(SKINRT_E_INVALID, "ctx is NULL");
+    if (bytes == 0) return SKINRT_OK;
+    if (!dev_src || !host_dst) return fail(SKINRT_E_INVALID, "skinrt_download: NULL pointer");
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return SKINRT_OK;
+}
+
+int skinrt_export_skin_uniform(skinrt_crowd* c, uint32_t instance, void* dst) {
+    if (int rc = check_crowd(c)) return rc;
+    if (!dst) return fail(SKINRT_E_INVALID, "dst is NULL");
+    if (instance >= c->I) return fail(SKINRT_E_RANGE, "instance out of range");
+    const uint32_t J = c->rig->host.J;
+    // assert!(items.len() <= MAX_JOINTS) — renderer/src/renderer/uniform/skin.rs:40,60
+    if (J > SKINRT_MAX_JOINTS_REFERENCE) return fail(SKINRT_E_LIMIT, "the reference palette holds at most 128 joints");
+    std::vector<float> rows((size_t)J * kPalFloats);
+    if (int rc = skinrt_download(c->ctx, c->palette.as<float>() + (size_t)instance * J * kPalFloats, rows.data(), rows.size() * 4)) return rc;
+    float* out = static_cast<float*>(dst);
+    std::memset(out, 0, (size_t)SKINRT_MAX_JOINTS_REFERENCE * SKINRT_SKIN_MATRIX_BYTES);
+    for (uint32_t j = 0; j < J; ++j) {
+        const float* e = &rows[(size_t)j * kPalFloats];
+        float* o = out + (size_t)j * 28;
+        for (int col = 0; col < 4; ++col) {  // transform: [[f32;4];4] column-major, last row 0,0,0,1
+            for (int r = 0; r < 3; ++r) o[col * 4 + r] = e[r * 4 + col];
+            o[col * 4 + 3] = col == 3 ? 1.0f : 0.0f;
+        }
+        for (int col = 0; col < 3; ++col) {  // normal: 3 columns padded with 0 (pad_vec3, :26-28)
+            for (int r = 0; r < 3; ++r) o[16 + col * 4 + r] = e[12 + r * 4 + col];
+            o[16 + col * 4 + 3] = 0.0f;
+        }
+    }
+    return SKINRT_OK;
+}
+
+int skinrt_export_interleaved(skinrt_crowd* c, uint32_t instance, uint32_t layout, const float* attr, void* dst) {
+    if (int rc = check_crowd(c)) return rc;
+    if (!dst) return fail(SKINRT_E_INVALID, "dst is NULL");
+    if (instance >= c->I) return fail(SKINRT_E_RANGE, "instance out of range");
+    if (layout > SKINRT_LAYOUT_TEXTURE_SKIN) return fail(SKINRT_E_INVALID, "unknown vertex layout");
+    const CompiledRig& h = c->rig->host;
+    const size_t V = h.V;
+    std::vector<float> p(V * 3), n(V * 3), t(V * 3);
+    const size_t off = (size_t)instance * V * 3;
+    if (int rc = skinrt_download(c->ctx, c->pos.as<float>() + off, p.data(), V * 12)) return rc;
+    if (int rc = skinrt_download(c->ctx, c->nrm.as<float>() + off, n.data(), V * 12)) return rc;
+    if (int rc = skinrt_download(c->ctx, c->tan.as<float>() + off, t.data(), V * 12)) return rc;
+    const uint32_t na = layout == SKINRT_LAYOUT_COLOR_SKIN ? 4 : 2;
+    const size_t stride = layout == SKINRT_LAYOUT_COLOR_SKIN ? 68 : 60;
+    uint8_t* o = static_cast<uint8_t*>(dst);
+    for (size_t v = 0; v < V; ++v, o += stride) {
+        uint8_t* q = o;
+        std::memcpy(q, &p[v * 3], 12); q += 12;
+        if (attr) std::memcpy(q, attr + v * na, na * 4); else std::memset(q, 0, na * 4);
+        q += na * 4;
+        std::memcpy(q, &n[v * 3], 12); q += 12;
+        std::memcpy(q, &t[v * 3], 12); q += 12;
+        std::memcpy(q, &h.joints0[v * 4], 8); q += 8;
+        std::memcpy(q, &h.weights0[v * 4], 16);
+    }
+    return SKINRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// device_types.hpp — kernel argument blocks shared by the API and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "rig_compile.hpp"
+
+namespace skinrt {
+
+// Device copies of CompiledRig's tables (rig_compile.hpp documents each).
+struct RigDev {
+    uint32_t N, J, V, K, M, clips, Cmax, levels, T;
+    const int32_t* parent;
+    const float* rest_trs;
+    const float* rest_mat;
+    const uint8_t* node_matrix;
+    const uint32_t* level_start;
+    const uint32_t* level_nodes;
+    const int32_t* node_chan;
+    const ChanRec* chans;
+    const uint32_t* clip_chan_count;
+    const float* times;
+    const float* values;
+    const uint32_t* joint_node;
+    const float* ibm;
+    const float* base;
+    const float* wts;
+    const uint16_t* lidx;
+    const uint32_t* tile_joint_start;
+    const uint32_t* tile_joints;
+    const uint8_t* tile_lds;
+    const uint32_t* mptr;
+    const uint16_t* mtgt;
+    const float* mdelta;
+};
+
+// Per-crowd state and outputs (HBM layout: DESIGN.md §3).
+struct CrowdDev {
+    uint32_t I;
+    const float* tau;      // [I]
+    const uint32_t* clip;  // [I]
+    const float* mw;       // [I][M]
+    const float* root;     // [I][12] rows, or nullptr
+    float* world;          // [I][N][12]
+    float* palette;        // [I][J][24]
+    uint32_t* keyidx;      // [I][Cmax]
+    float* pos;            // [I][V][3]
+    float* nrm;            // [I][V][3]
+    float* tan;            // [I][V][3]
+    float* aabb_part;      // [I][T][6]
+    float* aabb;           // [I][6]
+};
+
+// How the skinning grid is cut (computed once per crowd by plan_skin()).
+struct SkinPlan {
+    uint32_t range;     // instances per block (one block = one vertex tile x one instance range)
+    uint32_t ranges;    // ceil(I / range)
+    uint32_t batch;     // instances whose palettes are LDS-resident at once
+    uint32_t jt_shift;  // log2 of the padded tile joint-list length
+    uint32_t lds_bytes; // dynamic LDS per block
+    uint32_t exact;     // 1: contraction-free arithmetic (bit-equal to the fp32 oracle)
+    uint32_t normalize; // shader.wgsl:217-218 variant
+    uint32_t aabb;      // write per-(instance,tile) bounds
+};
+
+enum PosePath : uint32_t { kPoseWave = 0, kPoseSplit = 1 };
+
+// kernels_pose.hip
+hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t cubic_quirk, PosePath path, hipStream_t s);
+// kernels_skin.hip
+hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s);
+hipError_t launch_aabb_reduce(const RigDev& rig, const CrowdDev& cr, hipStream_t s);
+hipError_t launch_fill_morph_weights(float* mw, const float* defaults, uint32_t I, uint32_t M, hipStream_t s);
+
+}  // namespace skinrt

@@ -1,0 +1,305 @@
+// kernels_pose.hip — animation sampling, local TRS -> matrix, hierarchy propagation and the
+// joint palette for gfx950.
+//
+// Built with -ffp-contract=off (and the pragma below): every product and sum rounds once, in
+// the reference's order, so this stage is bit-equal to the fp32 oracle — which matters because
+// deep chains (config C5) and world*inverse_bind cancellation amplify any re-association.
+//
+// Matrices are affine 3x4, stored as 3 rows of 4 floats (row r = m[r][0..3], m[r][3] =
+// translation).  glam's full 4x4 products (node.rs:49-51) reduce to these forms exactly when
+// the last row is 0,0,0,1: the dropped terms are x*0 and +0.
+//
+// Two launch shapes:
+//   k_pose_wave   one 64-lane wavefront per instance, node matrices in LDS, nodes processed
+//                 level by level (topologically-levelled propagation), palette from LDS.
+//   split path    for rigs whose node table does not fit LDS or whose hierarchy is too deep to
+//                 level-step: k_sample_local (thread per instance x node), k_propagate_lane
+//                 (lane per instance walking the DFS order with the parent kept in registers),
+//                 k_palette (thread per instance x joint).
+#include "device_types.hpp"
+
+#pragma clang fp contract(off)
+
+namespace skinrt {
+
+namespace {
+
+struct Rows {
+    float4 r0, r1, r2;
+};
+
+// Interpolate::linear — renderer-asset/src/animation.rs:51-53
+__device__ __forceinline__ float lerp1(float a, float b, float omt, float t) { return a * omt + b * t; }
+
+// Sample one channel (a1-a4).  Returns the selected key.
+__device__ uint32_t sample_channel(const ChanRec ch, const float* __restrict__ times,
+                                   const float* __restrict__ values, float tau, uint32_t quirk, float out[4]) {
+    const float* tm = times + ch.time_off;
+    const float* v = values + ch.value_off;
+    const uint32_t n = ch.key_count;
+    const uint32_t w = ch.path == SKINRT_PATH_ROTATION ? 4u : 3u;
+    const bool cubic = ch.interp == SKINRT_INTERP_CUBICSPLINE;
+    uint32_t k;
+    bool clamped = true;
+    float u = 0.0f;
+    if (n == 1 || tau <= tm[0]) k = 0;
+    else if (tau >= tm[n - 1]) k = n - 1;
+    else {
+        uint32_t lo = 0, hi = n - 1;  // times[lo] <= tau < times[hi]
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (tm[mid] <= tau) lo = mid; else hi = mid;
+        }
+        k = lo;
+        clamped = false;
+    }
+    if (cubic) {
+        if (clamped) {
+            for (uint32_t i = 0; i < w; ++i) out[i] = v[(k * 3 + 1) * w + i];
+            return k;
+        }
+        const float t0 = tm[k], t1 = tm[k + 1];
+        u = (tau - t0) / (t1 - t0);
+        const float td = t1 - t0;
+        // Interpolate::cubic_spline — animation.rs:55-63 (t2 = t.powi(3) when quirk)
+        const float t3 = (u * u) * u;
+        const float t2 = quirk ? t3 : u * u;
+        const float c1 = 2.0f * t3 - 3.0f * t2 + 1.0f;
+        const float c2 = t3 - 2.0f * t2 + u;
+        const float c3 = -2.0f * t3 + 3.0f * t2;
+        const float c4 = t3 - t2;
+        for (uint32_t i = 0; i < w; ++i) {
+            const float vk = v[(k * 3 + 1) * w + i];
+            const float bk = v[(k * 3 + 2) * w + i];
+            const float vk1 = v[((k + 1) * 3 + 1) * w + i];
+            const float ak1 = v[((k + 1) * 3 + 0) * w + i];
+            const float first = vk * c1;
+            const float second = bk * td * c2;
+            const float third = vk1 * c3;
+            const float forth = ak1 * td * c4;
+            out[i] = first + second + third + forth;
+        }
+        return k;
+    }
+    if (clamped || ch.interp == SKINRT_INTERP_STEP) {
+        for (uint32_t i = 0; i < w; ++i) out[i] = v[k * w + i];
+        return k;
+    }
+    const float t0 = tm[k], t1 = tm[k + 1];
+    u = (tau - t0) / (t1 - t0);
+    const float omt = 1.0f - u;
+    for (uint32_t i = 0; i < w; ++i) out[i] = lerp1(v[k * w + i], v[(k + 1) * w + i], omt, u);
+    return k;
+}
+
+// impl From<DecomposedTransform> for Mat4 — renderer-asset/src/node.rs:47-53 with glam's
+// from_quat; T*R*S reduces to (R columns scaled by s, translation column = t).
+__device__ __forceinline__ Rows trs_to_rows(const float trs[10]) {
+    const float x = trs[3], y = trs[4], z = trs[5], w = trs[6];
+    const float x2 = x + x, y2 = y + y, z2 = z + z;
+    const float xx = x * x2, xy = x * y2, xz = x * z2;
+    const float yy = y * y2, yz = y * z2, zz = z * z2;
+    const float wx = w * x2, wy = w * y2, wz = w * z2;
+    const float sx = trs[7], sy = trs[8], sz = trs[9];
+    Rows m;
+    m.r0 = make_float4((1.0f - (yy + zz)) * sx, (xy - wz) * sy, (xz + wy) * sz, trs[0]);
+    m.r1 = make_float4((xy + wz) * sx, (1.0f - (xx + zz)) * sy, (yz - wx) * sz, trs[1]);
+    m.r2 = make_float4((xz - wy) * sx, (yz + wx) * sy, (1.0f - (xx + yy)) * sz, trs[2]);
+    return m;
+}
+
+// glam Mat4 * Mat4 for affine operands: out = a * b,
+// element = ((a.c0*b0 + a.c1*b1) + a.c2*b2) [+ a.c3 for the translation column].
+__device__ __forceinline__ float4 mul_row(const float4 a, const Rows& b) {
+    float4 o;
+    o.x = (a.x * b.r0.x + a.y * b.r1.x) + a.z * b.r2.x;
+    o.y = (a.x * b.r0.y + a.y * b.r1.y) + a.z * b.r2.y;
+    o.z = (a.x * b.r0.z + a.y * b.r1.z) + a.z * b.r2.z;
+    o.w = ((a.x * b.r0.w + a.y * b.r1.w) + a.z * b.r2.w) + a.w;
+    return o;
+}
+__device__ __forceinline__ Rows mul_affine(const Rows& a, const Rows& b) {
+    Rows o;
+    o.r0 = mul_row(a.r0, b);
+    o.r1 = mul_row(a.r1, b);
+    o.r2 = mul_row(a.r2, b);
+    return o;
+}
+
+__device__ __forceinline__ Rows load_rows(const float* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    Rows m;
+    m.r0 = q[0]; m.r1 = q[1]; m.r2 = q[2];
+    return m;
+}
+__device__ __forceinline__ void store_rows(float* p, const Rows& m) {
+    float4* q = reinterpret_cast<float4*>(p);
+    q[0] = m.r0; q[1] = m.r1; q[2] = m.r2;
+}
+
+// Local matrix of node n for one instance (a5, a6) + key indices of the channels it sampled.
+__device__ Rows node_local(const RigDev& rig, uint32_t clip, bool has_clip, uint32_t n, float tau,
+                           uint32_t quirk, uint32_t* __restrict__ keyrow) {
+    float trs[10];
+    const float* rest = rig.rest_trs + (size_t)n * 10;
+#pragma unroll
+    for (int e = 0; e < 10; ++e) trs[e] = rest[e];
+    bool animated = false;
+    if (has_clip) {
+        const int32_t* nc = rig.node_chan + ((size_t)clip * rig.N + n) * 3;
+#pragma unroll
+        for (int path = 0; path < 3; ++path) {
+            const int32_t c = nc[path];
+            if (c >= 0) {
+                animated = true;
+                const ChanRec ch = rig.chans[c];
+                float v[4];
+                const uint32_t k = sample_channel(ch, rig.times, rig.values, tau, quirk, v);
+                keyrow[ch.local] = k;
+                if (path == SKINRT_PATH_TRANSLATION) { trs[0] = v[0]; trs[1] = v[1]; trs[2] = v[2]; }
+                else if (path == SKINRT_PATH_ROTATION) { trs[3] = v[0]; trs[4] = v[1]; trs[5] = v[2]; trs[6] = v[3]; }
+                else { trs[7] = v[0]; trs[8] = v[1]; trs[9] = v[2]; }
+            }
+        }
+    }
+    // NodeTransform::Matrix stays a matrix unless a channel forces the TRS form (node.rs:55-62, :73-87)
+    if (rig.node_matrix[n] && !animated) return load_rows(rig.rest_mat + (size_t)n * 12);
+    return trs_to_rows(trs);
+}
+
+// a8 + a9: joint = world * inverse_bind; normal = Mat3::from_mat4(joint.inverse().transpose())
+// (renderer/src/renderer/uniform/skin.rs:30-37).  glam's cofactor inverse reduces, for an affine
+// matrix, to the 2x2 minors below (the dropped factors are *1 and -0), in the same order.
+__device__ __forceinline__ void palette_entry(const Rows& world, const Rows& ibm, float* __restrict__ out24) {
+    const Rows m = mul_affine(world, ibm);
+    // glam naming: mCR = column C, row R
+    const float m00 = m.r0.x, m10 = m.r0.y, m20 = m.r0.z;
+    const float m01 = m.r1.x, m11 = m.r1.y, m21 = m.r1.z;
+    const float m02 = m.r2.x, m12 = m.r2.y, m22 = m.r2.z;
+    const float i00 = m11 * m22 - m12 * m21, i01 = m01 * m22 - m02 * m21, i02 = m01 * m12 - m02 * m11;
+    const float i10 = m10 * m22 - m12 * m20, i11 = m00 * m22 - m02 * m20, i12 = m00 * m12 - m02 * m10;
+    const float i20 = m10 * m21 - m11 * m20, i21 = m00 * m21 - m01 * m20, i22 = m00 * m11 - m01 * m10;
+    const float dot1 = (m00 * i00 + m01 * (-i10)) + m02 * i20;
+    const float rcp = 1.0f / dot1;
+    float4* o = reinterpret_cast<float4*>(out24);
+    o[0] = m.r0; o[1] = m.r1; o[2] = m.r2;
+    o[3] = make_float4(i00 * rcp, (-i01) * rcp, i02 * rcp, 0.0f);
+    o[4] = make_float4((-i10) * rcp, i11 * rcp, (-i12) * rcp, 0.0f);
+    o[5] = make_float4(i20 * rcp, (-i21) * rcp, i22 * rcp, 0.0f);
+}
+
+__device__ __forceinline__ void clear_unused_keys(const RigDev& rig, uint32_t clip, bool has_clip,
+                                                  uint32_t* __restrict__ keyrow, uint32_t lane, uint32_t stride) {
+    const uint32_t used = has_clip ? rig.clip_chan_count[clip] : 0u;
+    for (uint32_t c = used + lane; c < rig.Cmax; c += stride) keyrow[c] = 0xFFFFFFFFu;
+}
+
+// ---- wavefront-per-instance ------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_pose_wave(const RigDev rig, const CrowdDev cr, const uint32_t quirk) {
+    extern __shared__ float4 node_s[];  // [N][3] rows
+    const uint32_t i = blockIdx.x, lane = threadIdx.x;
+    const uint32_t clip = cr.clip[i];
+    const bool has_clip = clip < rig.clips;
+    const float tau = cr.tau[i];
+    uint32_t* keyrow = cr.keyidx + (size_t)i * rig.Cmax;
+    clear_unused_keys(rig, clip, has_clip, keyrow, lane, 64);
+
+    for (uint32_t n = lane; n < rig.N; n += 64) {
+        const Rows l = node_local(rig, clip, has_clip, n, tau, quirk, keyrow);
+        node_s[n * 3 + 0] = l.r0; node_s[n * 3 + 1] = l.r1; node_s[n * 3 + 2] = l.r2;
+    }
+    __syncthreads();
+    Rows root;
+    if (cr.root) root = load_rows(cr.root + (size_t)i * 12);
+    for (uint32_t lv = cr.root ? 0u : 1u; lv < rig.levels; ++lv) {
+        const uint32_t e = rig.level_start[lv + 1];
+        for (uint32_t idx = rig.level_start[lv] + lane; idx < e; idx += 64) {
+            const uint32_t n = rig.level_nodes[idx];
+            const int32_t p = rig.parent[n];
+            Rows l, pw;
+            l.r0 = node_s[n * 3 + 0]; l.r1 = node_s[n * 3 + 1]; l.r2 = node_s[n * 3 + 2];
+            if (p >= 0) { pw.r0 = node_s[p * 3 + 0]; pw.r1 = node_s[p * 3 + 1]; pw.r2 = node_s[p * 3 + 2]; }
+            else pw = root;
+            const Rows w = mul_affine(pw, l);
+            node_s[n * 3 + 0] = w.r0; node_s[n * 3 + 1] = w.r1; node_s[n * 3 + 2] = w.r2;
+        }
+        __syncthreads();
+    }
+    float4* wout = reinterpret_cast<float4*>(cr.world + (size_t)i * rig.N * 12);
+    for (uint32_t e = lane; e < rig.N * 3; e += 64) wout[e] = node_s[e];
+    for (uint32_t j = lane; j < rig.J; j += 64) {
+        const uint32_t n = rig.joint_node[j];
+        Rows w;
+        w.r0 = node_s[n * 3 + 0]; w.r1 = node_s[n * 3 + 1]; w.r2 = node_s[n * 3 + 2];
+        palette_entry(w, load_rows(rig.ibm + (size_t)j * 12), cr.palette + ((size_t)i * rig.J + j) * kPalFloats);
+    }
+}
+
+// ---- split path -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample_local(const RigDev rig, const CrowdDev cr, const uint32_t quirk) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (uint64_t)cr.I * rig.N) return;
+    const uint32_t i = (uint32_t)(g / rig.N), n = (uint32_t)(g % rig.N);
+    const uint32_t clip = cr.clip[i];
+    const bool has_clip = clip < rig.clips;
+    uint32_t* keyrow = cr.keyidx + (size_t)i * rig.Cmax;
+    if (n == 0) clear_unused_keys(rig, clip, has_clip, keyrow, 0, 1);
+    const Rows l = node_local(rig, clip, has_clip, n, cr.tau[i], quirk, keyrow);
+    store_rows(cr.world + g * 12, l);
+}
+
+// One lane per instance walks the DFS pre-order; the previous node's world matrix stays in
+// registers (in pre-order the parent is usually the previous node), the next local matrix is
+// prefetched, so a 4096-deep chain costs one dependent FMA group per node, not a memory trip.
+__global__ __launch_bounds__(64) void k_propagate_lane(const RigDev rig, const CrowdDev cr) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= cr.I) return;
+    float* w = cr.world + (size_t)i * rig.N * 12;
+    Rows root;
+    const bool has_root = cr.root != nullptr;
+    if (has_root) root = load_rows(cr.root + (size_t)i * 12);
+    Rows prev;
+    Rows next = load_rows(w);
+    for (uint32_t n = 0; n < rig.N; ++n) {
+        const Rows l = next;
+        if (n + 1 < rig.N) next = load_rows(w + (size_t)(n + 1) * 12);
+        const int32_t p = rig.parent[n];
+        Rows out;
+        if (p < 0) out = has_root ? mul_affine(root, l) : l;
+        else {
+            const Rows pw = (p == (int32_t)n - 1) ? prev : load_rows(w + (size_t)p * 12);
+            out = mul_affine(pw, l);
+        }
+        store_rows(w + (size_t)n * 12, out);
+        prev = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_palette(const RigDev rig, const CrowdDev cr) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (uint64_t)cr.I * rig.J) return;
+    const uint32_t i = (uint32_t)(g / rig.J), j = (uint32_t)(g % rig.J);
+    const Rows w = load_rows(cr.world + ((size_t)i * rig.N + rig.joint_node[j]) * 12);
+    palette_entry(w, load_rows(rig.ibm + (size_t)j * 12), cr.palette + g * kPalFloats);
+}
+
+}  // namespace
+
+hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t quirk, PosePath path, hipStream_t s) {
+    if (cr.I == 0) return hipSuccess;
+    if (path == kPoseWave) {
+        const size_t lds = (size_t)rig.N * 48;
+        hipLaunchKernelGGL(k_pose_wave, dim3(cr.I), dim3(64), lds, s, rig, cr, quirk);
+        return hipGetLastError();
+    }
+    const uint64_t in = (uint64_t)cr.I * rig.N;
+    hipLaunchKernelGGL(k_sample_local, dim3((uint32_t)((in + 255) / 256)), dim3(256), 0, s, rig, cr, quirk);
+    hipLaunchKernelGGL(k_propagate_lane, dim3((cr.I + 63) / 64), dim3(64), 0, s, rig, cr);
+    if (rig.J) {
+        const uint64_t ij = (uint64_t)cr.I * rig.J;
+        hipLaunchKernelGGL(k_palette, dim3((uint32_t)((ij + 255) / 256)), dim3(256), 0, s, rig, cr);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace skinrt

@@ -1,0 +1,340 @@
+// rig_compile.cpp — validate the flat loader output and build the kernel tables.
+// Host-only; compiled with -ffp-contract=off so the one piece of arithmetic here
+// (Matrix -> TRS decomposition) rounds like glam's scalar code.
+#include "rig_compile.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace skinrt {
+
+namespace {
+
+struct Fail {
+    int code;
+    std::string msg;
+};
+
+#define REQUIRE(cond, code, text)            \
+    do {                                     \
+        if (!(cond)) throw Fail{code, text}; \
+    } while (0)
+
+bool finite_all(const float* p, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+        if (!std::isfinite(p[i])) return false;
+    return true;
+}
+
+bool affine_last_row(const float* m) {  // column-major: row 3 = m[3], m[7], m[11], m[15]
+    return m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f;
+}
+
+void rows_from_cols(const float* m16, float* r12) {  // first three rows, row-major
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) r12[r * 4 + c] = m16[c * 4 + r];
+}
+
+float det4(const float* m) {  // glam Mat4::determinant, scalar path
+    float m00 = m[0], m01 = m[1], m02 = m[2], m03 = m[3];
+    float m10 = m[4], m11 = m[5], m12 = m[6], m13 = m[7];
+    float m20 = m[8], m21 = m[9], m22 = m[10], m23 = m[11];
+    float m30 = m[12], m31 = m[13], m32 = m[14], m33 = m[15];
+    float a2323 = m22 * m33 - m23 * m32;
+    float a1323 = m21 * m33 - m23 * m31;
+    float a1223 = m21 * m32 - m22 * m31;
+    float a0323 = m20 * m33 - m23 * m30;
+    float a0223 = m20 * m32 - m22 * m30;
+    float a0123 = m20 * m31 - m21 * m30;
+    return m00 * (m11 * a2323 - m12 * a1323 + m13 * a1223) - m01 * (m10 * a2323 - m12 * a0323 + m13 * a0223) +
+           m02 * (m10 * a1323 - m11 * a0323 + m13 * a0123) - m03 * (m10 * a1223 - m11 * a0223 + m12 * a0123);
+}
+
+float len3(const float* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+}  // namespace
+
+// glam Mat4::to_scale_rotation_translation + Quat::from_rotation_axes (Mike Day's method),
+// the conversion behind `impl From<NodeTransform> for DecomposedTransform` (node.rs:73-87).
+void decompose_affine(const float* m, float* t, float* q, float* s) {
+    float det = det4(m);
+    float sg = std::signbit(det) ? -1.0f : 1.0f;
+    s[0] = len3(m + 0) * sg;
+    s[1] = len3(m + 4);
+    s[2] = len3(m + 8);
+    float is0 = 1.0f / s[0], is1 = 1.0f / s[1], is2 = 1.0f / s[2];
+    float m00 = m[0] * is0, m01 = m[1] * is0, m02 = m[2] * is0;
+    float m10 = m[4] * is1, m11 = m[5] * is1, m12 = m[6] * is1;
+    float m20 = m[8] * is2, m21 = m[9] * is2, m22 = m[10] * is2;
+    if (m22 <= 0.0f) {
+        float dif10 = m11 - m00, omm22 = 1.0f - m22;
+        if (dif10 <= 0.0f) {
+            float f = omm22 - dif10, i4 = 0.5f / std::sqrt(f);
+            q[0] = f * i4; q[1] = (m01 + m10) * i4; q[2] = (m02 + m20) * i4; q[3] = (m12 - m21) * i4;
+        } else {
+            float f = omm22 + dif10, i4 = 0.5f / std::sqrt(f);
+            q[0] = (m01 + m10) * i4; q[1] = f * i4; q[2] = (m12 + m21) * i4; q[3] = (m20 - m02) * i4;
+        }
+    } else {
+        float sum10 = m11 + m00, opm22 = 1.0f + m22;
+        if (sum10 <= 0.0f) {
+            float f = opm22 - sum10, i4 = 0.5f / std::sqrt(f);
+            q[0] = (m02 + m20) * i4; q[1] = (m12 + m21) * i4; q[2] = f * i4; q[3] = (m01 - m10) * i4;
+        } else {
+            float f = opm22 + sum10, i4 = 0.5f / std::sqrt(f);
+            q[0] = (m12 - m21) * i4; q[1] = (m20 - m02) * i4; q[2] = (m01 - m10) * i4; q[3] = f * i4;
+        }
+    }
+    t[0] = m[12]; t[1] = m[13]; t[2] = m[14];
+}
+
+static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, CompiledRig& r) {
+    REQUIRE(d != nullptr, SKINRT_E_INVALID, "rig desc is NULL");
+    REQUIRE(d->struct_size == sizeof(skinrt_rig_desc), SKINRT_E_INVALID, "skinrt_rig_desc.struct_size mismatch");
+    const uint32_t N = d->node_count, J = d->joint_count, V = d->vertex_count, K = d->set_count, M = d->target_count;
+    r.N = N; r.J = J; r.V = V; r.K = K; r.M = M; r.clips = d->clip_count;
+    REQUIRE(N >= 1, SKINRT_E_INVALID, "rig has no nodes");
+    REQUIRE(d->parent && d->translation && d->rotation && d->scale, SKINRT_E_INVALID, "node arrays missing");
+    REQUIRE(M <= 65535, SKINRT_E_INVALID, "more than 65535 morph targets");
+    REQUIRE(J <= 65536, SKINRT_E_INVALID, "joint indices are u16: at most 65536 joints");
+    if (cfg && cfg->reference_limits) {
+        REQUIRE(J <= SKINRT_MAX_JOINTS_REFERENCE, SKINRT_E_LIMIT, "reference_limits: more than 128 joints (uniform/skin.rs:10)");
+        REQUIRE(K <= 1, SKINRT_E_LIMIT, "reference_limits: the reference shader reads joint/weight set 0 only");
+    }
+
+    // ---- nodes ------------------------------------------------------------------------
+    r.parent.assign(d->parent, d->parent + N);
+    std::vector<uint32_t> depth(N, 0);
+    for (uint32_t n = 0; n < N; ++n) {
+        int32_t p = r.parent[n];
+        REQUIRE(p >= -1 && p < (int32_t)n, SKINRT_E_INVALID, "parent[] is not a DFS pre-order forest (need -1 <= parent[n] < n)");
+        depth[n] = p < 0 ? 0 : depth[p] + 1;
+    }
+    REQUIRE(finite_all(d->translation, (size_t)N * 3) && finite_all(d->rotation, (size_t)N * 4) &&
+                finite_all(d->scale, (size_t)N * 3), SKINRT_E_INVALID, "non-finite node transform");
+    r.rest_trs.resize((size_t)N * 10);
+    r.rest_mat.assign((size_t)N * 12, 0.0f);
+    r.node_matrix.assign(N, 0);
+    for (uint32_t n = 0; n < N; ++n) {
+        float* trs = &r.rest_trs[(size_t)n * 10];
+        std::memcpy(trs, d->translation + n * 3, 12);
+        std::memcpy(trs + 3, d->rotation + n * 4, 16);
+        std::memcpy(trs + 7, d->scale + n * 3, 12);
+        if (d->has_matrix && d->has_matrix[n]) {
+            REQUIRE(d->matrix != nullptr, SKINRT_E_INVALID, "has_matrix set but matrix is NULL");
+            const float* m = d->matrix + (size_t)n * 16;
+            REQUIRE(finite_all(m, 16), SKINRT_E_INVALID, "non-finite node matrix");
+            REQUIRE(affine_last_row(m), SKINRT_E_NONAFFINE, "node matrix last row is not 0,0,0,1");
+            r.node_matrix[n] = 1;
+            rows_from_cols(m, &r.rest_mat[(size_t)n * 12]);
+            decompose_affine(m, trs, trs + 3, trs + 7);
+        }
+    }
+    uint32_t levels = 0;
+    for (uint32_t n = 0; n < N; ++n) levels = std::max(levels, depth[n] + 1);
+    r.levels = levels;
+    r.level_start.assign(levels + 1, 0);
+    for (uint32_t n = 0; n < N; ++n) r.level_start[depth[n] + 1]++;
+    for (uint32_t l = 0; l < levels; ++l) r.level_start[l + 1] += r.level_start[l];
+    r.level_nodes.resize(N);
+    {
+        std::vector<uint32_t> cur(r.level_start.begin(), r.level_start.end() - 1);
+        for (uint32_t n = 0; n < N; ++n) r.level_nodes[cur[depth[n]]++] = n;
+    }
+
+    // ---- clips --------------------------------------------------------------------------
+    REQUIRE(r.clips == 0 || d->clips, SKINRT_E_INVALID, "clips is NULL");
+    r.node_chan.assign((size_t)r.clips * N * 3, -1);
+    r.clip_chan_count.resize(r.clips);
+    r.Cmax = 0;
+    for (uint32_t c = 0; c < r.clips; ++c) {
+        const skinrt_clip_desc& cl = d->clips[c];
+        REQUIRE(cl.channel_count == 0 || cl.channels, SKINRT_E_INVALID, "clip channels is NULL");
+        REQUIRE(cl.channel_count <= 65535, SKINRT_E_INVALID, "more than 65535 channels in a clip");
+        r.clip_chan_count[c] = cl.channel_count;
+        r.Cmax = std::max(r.Cmax, cl.channel_count);
+        for (uint32_t k = 0; k < cl.channel_count; ++k) {
+            const skinrt_channel_desc& ch = cl.channels[k];
+            REQUIRE(ch.target_node < N, SKINRT_E_RANGE, "channel target_node out of range");
+            REQUIRE(ch.path <= SKINRT_PATH_SCALE, SKINRT_E_INVALID, "channel path invalid (MorphTargetWeights is todo!() in the reference, loader/gltf/mod.rs:1312)");
+            REQUIRE(ch.interpolation <= SKINRT_INTERP_CUBICSPLINE, SKINRT_E_INVALID, "channel interpolation invalid");
+            REQUIRE(ch.key_count >= 1 && ch.times && ch.values, SKINRT_E_INVALID, "channel without keyframes");
+            const uint32_t w = ch.path == SKINRT_PATH_ROTATION ? 4 : 3;
+            const uint32_t per_key = (ch.interpolation == SKINRT_INTERP_CUBICSPLINE ? 3 : 1) * w;
+            REQUIRE(finite_all(ch.times, ch.key_count), SKINRT_E_INVALID, "non-finite key time");
+            for (uint32_t i = 1; i < ch.key_count; ++i)
+                REQUIRE(ch.times[i] >= ch.times[i - 1], SKINRT_E_INVALID, "key times are not sorted");
+            int32_t& slot = r.node_chan[((size_t)c * N + ch.target_node) * 3 + ch.path];
+            REQUIRE(slot < 0, SKINRT_E_INVALID, "two channels of one clip target the same node property");
+            slot = (int32_t)r.chans.size();
+            ChanRec rec;
+            rec.key_count = ch.key_count;
+            rec.time_off = (uint32_t)r.times.size();
+            rec.value_off = (uint32_t)r.values.size();
+            rec.local = (uint16_t)k;
+            rec.interp = ch.interpolation;
+            rec.path = ch.path;
+            r.chans.push_back(rec);
+            r.times.insert(r.times.end(), ch.times, ch.times + ch.key_count);
+            r.values.insert(r.values.end(), ch.values, ch.values + (size_t)ch.key_count * per_key);
+            REQUIRE(r.values.size() < (1ull << 32), SKINRT_E_INVALID, "keyframe pool exceeds 2^32 floats");
+        }
+    }
+
+    // ---- skin ----------------------------------------------------------------------------
+    REQUIRE(J == 0 || d->joint_node, SKINRT_E_INVALID, "joint_node is NULL");
+    r.joint_node.assign(d->joint_node, d->joint_node + J);
+    r.ibm.resize((size_t)J * 12);
+    for (uint32_t j = 0; j < J; ++j) {
+        REQUIRE(r.joint_node[j] < N, SKINRT_E_RANGE, "joint_node out of range");
+        static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        const float* m = d->inverse_bind ? d->inverse_bind + (size_t)j * 16 : ident;
+        REQUIRE(finite_all(m, 16), SKINRT_E_INVALID, "non-finite inverse bind matrix");
+        REQUIRE(affine_last_row(m), SKINRT_E_NONAFFINE, "inverse bind matrix last row is not 0,0,0,1");
+        rows_from_cols(m, &r.ibm[(size_t)j * 12]);
+    }
+
+    // ---- mesh ------------------------------------------------------------------------------
+    const uint32_t TV = kTileVerts;
+    const uint32_t T = (V + TV - 1) / TV;
+    r.T = T;
+    r.tangent_stride = d->tangent_stride ? d->tangent_stride : 3;
+    if (V) {
+        REQUIRE(d->position && d->normal && d->tangent, SKINRT_E_INVALID, "vertex arrays missing (reference: expect(\"No positions in primitive\"), loader/gltf/mod.rs:1050)");
+        REQUIRE(r.tangent_stride == 3 || r.tangent_stride == 4, SKINRT_E_INVALID, "tangent_stride must be 3 or 4");
+        REQUIRE(K >= 1 && K <= 4 && d->joints && d->weights, SKINRT_E_INVALID, "need 1..4 joint/weight sets");
+        REQUIRE(J >= 1, SKINRT_E_INVALID, "skinned vertices but no joints");
+        for (uint32_t k = 0; k < K; ++k) REQUIRE(d->joints[k] && d->weights[k], SKINRT_E_INVALID, "joint/weight set is NULL");
+    }
+    const uint32_t W = 4 * K;
+    r.base.assign((size_t)T * 9 * TV, 0.0f);
+    r.wts.assign((size_t)T * W * TV, 0.0f);
+    r.lidx.assign((size_t)T * W * TV, 0);
+    r.tile_joint_start.assign(T + 1, 0);
+    r.tile_lds.assign(T, 1);
+    r.max_tile_joints = r.max_tile_joints_any = 0;
+    r.lds_tiles = 0;
+    std::vector<uint32_t> stamp(J ? J : 1, UINT32_MAX), local_of(J ? J : 1, 0), list;
+    for (uint32_t t = 0; t < T; ++t) {
+        const uint32_t v0 = t * TV, v1 = std::min(V, v0 + TV);
+        float* b = &r.base[(size_t)t * 9 * TV];
+        for (uint32_t v = v0; v < v1; ++v) {
+            const uint32_t l = v - v0;
+            for (int e = 0; e < 3; ++e) {
+                b[(0 + e) * TV + l] = d->position[(size_t)v * 3 + e];
+                b[(3 + e) * TV + l] = d->normal[(size_t)v * 3 + e];
+                b[(6 + e) * TV + l] = d->tangent[(size_t)v * r.tangent_stride + e];
+            }
+        }
+        // tile joint list: joints referenced with a non-zero weight
+        list.clear();
+        for (uint32_t v = v0; v < v1; ++v)
+            for (uint32_t k = 0; k < K; ++k)
+                for (uint32_t c = 0; c < 4; ++c) {
+                    const float w = d->weights[k][(size_t)v * 4 + c];
+                    const uint32_t j = d->joints[k][(size_t)v * 4 + c];
+                    REQUIRE(std::isfinite(w), SKINRT_E_INVALID, "non-finite joint weight");
+                    if (w == 0.0f) continue;  // contributes exactly 0 whatever the index
+                    REQUIRE(j < J, SKINRT_E_RANGE, "vertex joint index out of range");
+                    if (stamp[j] != t) { stamp[j] = t; list.push_back(j); }
+                }
+        if (list.empty() && J) { list.push_back(0); stamp[0] = t; }
+        std::sort(list.begin(), list.end());
+        for (uint32_t i = 0; i < list.size(); ++i) local_of[list[i]] = i;
+        const bool lds = list.size() <= kTileJointCap;
+        r.tile_lds[t] = lds ? 1 : 0;
+        r.lds_tiles += lds ? 1 : 0;
+        r.max_tile_joints_any = std::max<uint32_t>(r.max_tile_joints_any, (uint32_t)list.size());
+        if (lds) r.max_tile_joints = std::max<uint32_t>(r.max_tile_joints, (uint32_t)list.size());
+        r.tile_joint_start[t + 1] = r.tile_joint_start[t] + (uint32_t)list.size();
+        r.tile_joints.insert(r.tile_joints.end(), list.begin(), list.end());
+        float* wt = &r.wts[(size_t)t * W * TV];
+        uint16_t* li = &r.lidx[(size_t)t * W * TV];
+        for (uint32_t v = v0; v < v1; ++v)
+            for (uint32_t k = 0; k < K; ++k)
+                for (uint32_t c = 0; c < 4; ++c) {
+                    const float w = d->weights[k][(size_t)v * 4 + c];
+                    const uint32_t j = d->joints[k][(size_t)v * 4 + c];
+                    const uint32_t a = k * 4 + c, l = v - v0;
+                    wt[a * TV + l] = w;
+                    // zero-weight influences read the tile's first joint: 0 * finite = 0 either way
+                    const uint32_t jj = (w == 0.0f) ? list[0] : j;
+                    li[a * TV + l] = (uint16_t)(lds ? local_of[jj] : jj);
+                }
+    }
+    if (V) {
+        r.joints0.assign(d->joints[0], d->joints[0] + (size_t)V * 4);
+        r.weights0.assign(d->weights[0], d->weights[0] + (size_t)V * 4);
+    }
+
+    // ---- morph targets -> per-vertex lists (targets ascending) ----------------------------
+    REQUIRE(M == 0 || d->targets, SKINRT_E_INVALID, "targets is NULL");
+    r.default_weights.assign(M, 0.0f);
+    if (d->default_weights) r.default_weights.assign(d->default_weights, d->default_weights + M);
+    r.mptr.assign((size_t)T * TV + 1, 0);
+    auto for_each_entry = [&](auto&& fn) {
+        for (uint32_t m = 0; m < M; ++m) {
+            const skinrt_morph_target_desc& tg = d->targets[m];
+            if (!tg.indices) REQUIRE(tg.count == V, SKINRT_E_INVALID, "dense morph target count != vertex_count");
+            uint32_t prev = 0;
+            for (uint32_t row = 0; row < tg.count; ++row) {
+                uint32_t v = tg.indices ? tg.indices[row] : row;
+                if (tg.indices) {
+                    REQUIRE(v < V, SKINRT_E_RANGE, "morph target vertex index out of range");
+                    REQUIRE(row == 0 || v > prev, SKINRT_E_INVALID, "morph target indices must be strictly increasing");
+                    prev = v;
+                }
+                float dl[9];
+                for (int e = 0; e < 3; ++e) {
+                    dl[e] = tg.position ? tg.position[(size_t)row * 3 + e] : 0.0f;
+                    dl[3 + e] = tg.normal ? tg.normal[(size_t)row * 3 + e] : 0.0f;
+                    dl[6 + e] = tg.tangent ? tg.tangent[(size_t)row * r.tangent_stride + e] : 0.0f;
+                }
+                bool nz = false;
+                for (int e = 0; e < 9; ++e) {
+                    REQUIRE(std::isfinite(dl[e]), SKINRT_E_INVALID, "non-finite morph delta");
+                    nz |= dl[e] != 0.0f;
+                }
+                if (nz) fn(v, m, dl);  // an all-zero delta adds exactly 0: dropped
+            }
+        }
+    };
+    for_each_entry([&](uint32_t v, uint32_t, const float*) { r.mptr[v + 1]++; });
+    for (size_t v = 0; v < (size_t)T * TV; ++v) r.mptr[v + 1] += r.mptr[v];
+    const size_t E = r.mptr[(size_t)T * TV];
+    r.mtgt.resize(E);
+    r.mdelta.resize(E * 9);
+    {
+        std::vector<uint32_t> cur(r.mptr.begin(), r.mptr.end() - 1);
+        for_each_entry([&](uint32_t v, uint32_t m, const float* dl) {
+            const uint32_t e = cur[v]++;
+            r.mtgt[e] = (uint16_t)m;
+            std::memcpy(&r.mdelta[(size_t)e * 9], dl, 36);
+        });
+    }
+}
+
+int compile_rig(const skinrt_rig_desc* desc, const skinrt_config* cfg, CompiledRig& out, std::string& err) {
+    try {
+        compile_impl(desc, cfg, out);
+    } catch (const Fail& f) {
+        err = f.msg;
+        return f.code;
+    } catch (const std::bad_alloc&) {
+        err = "out of host memory while compiling rig";
+        return SKINRT_E_NOMEM;
+    }
+    return SKINRT_OK;
+}
+
+void fill_rig_info(const CompiledRig& r, uint64_t device_bytes, skinrt_rig_info* info) {
+    std::memset(info, 0, sizeof *info);
+    info->node_count = r.N; info->joint_count = r.J; info->vertex_count = r.V; info->set_count = r.K;
+    info->target_count = r.M; info->clip_count = r.clips; info->level_count = r.levels;
+    info->tile_count = r.T; info->tile_vertices = kTileVerts; info->max_tile_joints = r.max_tile_joints_any;
+    info->lds_tiles = r.lds_tiles; info->max_channels = r.Cmax; info->morph_entries = r.mtgt.size();
+    info->device_bytes = device_bytes;
+}
+
+}  // namespace skinrt

@@ -1,0 +1,71 @@
+// rig_compile.hpp — host-side validation + compilation of the flat loader output
+// (skinrt_rig_desc) into the tables the HIP kernels read.  Pure host C++; no device calls.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/skinrt.h"
+
+namespace skinrt {
+
+constexpr uint32_t kTileVerts = 256;   // vertices per skinning tile = threads per block
+constexpr uint32_t kTileJointCap = 64; // largest tile-local joint list that is LDS-staged
+constexpr uint32_t kPalFloats = 24;    // palette entry: 3x4 joint rows + 3x4 normal rows
+
+// one animation channel, keyframes in the shared times[] / values[] pools
+struct ChanRec {
+    uint32_t key_count;
+    uint32_t time_off;   // into times[]
+    uint32_t value_off;  // into values[]
+    uint16_t local;      // index of the channel inside its clip (key_index column)
+    uint8_t interp;      // SKINRT_INTERP_*
+    uint8_t path;        // SKINRT_PATH_*
+};
+
+struct CompiledRig {
+    uint32_t N = 0, J = 0, V = 0, K = 0, M = 0, clips = 0, Cmax = 0, levels = 0, T = 0;
+    uint32_t tangent_stride = 3;
+    // nodes (DFS pre-order)
+    std::vector<int32_t> parent;        // [N]
+    std::vector<float> rest_trs;        // [N][10] t3 q4 s3 (Matrix nodes: decomposed, node.rs:76-82)
+    std::vector<float> rest_mat;        // [N][12] 3 rows x 4 (Matrix nodes only, else unused)
+    std::vector<uint8_t> node_matrix;   // [N] 1 = NodeTransform::Matrix
+    std::vector<uint32_t> level_start;  // [levels+1]
+    std::vector<uint32_t> level_nodes;  // [N] nodes ordered by depth (stable)
+    // clips
+    std::vector<int32_t> node_chan;     // [clips][N][3] global channel index or -1
+    std::vector<ChanRec> chans;
+    std::vector<uint32_t> clip_chan_count;  // [clips]
+    std::vector<float> times, values;
+    // skin
+    std::vector<uint32_t> joint_node;   // [J]
+    std::vector<float> ibm;             // [J][12] 3 rows x 4
+    // mesh, tiled: [T][attr][kTileVerts]
+    std::vector<float> base;            // [T][9][256]  px py pz nx ny nz tx ty tz
+    std::vector<float> wts;             // [T][4K][256]
+    std::vector<uint16_t> lidx;         // [T][4K][256] tile-local joint index (LDS tiles) or global joint id
+    std::vector<uint32_t> tile_joint_start;  // [T+1]
+    std::vector<uint32_t> tile_joints;       // concatenated tile joint lists (global ids, ascending)
+    std::vector<uint8_t> tile_lds;           // [T] 1 = joint list fits kTileJointCap
+    uint32_t max_tile_joints = 0;            // over LDS tiles
+    uint32_t max_tile_joints_any = 0;
+    uint32_t lds_tiles = 0;
+    // morph: per-vertex lists of (target, delta9), targets ascending
+    std::vector<uint32_t> mptr;         // [T*256+1]
+    std::vector<uint16_t> mtgt;         // [E]
+    std::vector<float> mdelta;          // [E][9]
+    std::vector<float> default_weights; // [M]
+    // kept for skinrt_export_interleaved
+    std::vector<uint16_t> joints0;      // [V][4]
+    std::vector<float> weights0;        // [V][4]
+};
+
+// Returns SKINRT_OK or a negative SKINRT_E_* with `err` describing the problem.
+int compile_rig(const skinrt_rig_desc* desc, const skinrt_config* cfg, CompiledRig& out, std::string& err);
+void fill_rig_info(const CompiledRig& r, uint64_t device_bytes, skinrt_rig_info* info);
+
+// glam Mat4::to_scale_rotation_translation, restated (node.rs:76-82); m column-major [16].
+void decompose_affine(const float* m, float* t3, float* q4, float* s3);
+
+}  // namespace skinrt

@@ -1,0 +1,215 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): bit-exact keyframe selection / joint gathers / node order;
+1e-5 relative / 1e-6 absolute for matrices, positions, normals.  Stronger where available: the
+pose stage is contraction-free and must EQUAL the fp32 oracle; with exact_arithmetic=1 the
+skinning stage must too.  Parity is "unpinned" w.r.t. the reference itself (no reference test
+or fixture covers this path: SURVEY.md §4) — the oracle is the CPU restatement in oracle/.
+"""
+import numpy as np
+import pytest
+
+from renderer_amd import abi, api, synth
+from tests.helpers import assert_close, assert_equal, run_gpu, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+FLOAT_OUT = ("position", "normal", "tangent")
+
+
+def _check_all(got, ref, exact_pose=True, exact_skin=False, tag=""):
+    assert_equal(got["key_index"], ref["key_index"], tag + "key_index")
+    if exact_pose:
+        assert_equal(got["world"], ref["world"], tag + "world")
+        assert_equal(got["palette"], ref["palette"], tag + "palette")
+    else:
+        assert_close(got["world"], ref["world"], tag + "world")
+        assert_close(got["palette"], ref["palette"], tag + "palette")
+    for k in FLOAT_OUT:
+        if exact_skin:
+            assert_equal(got[k], ref[k], tag + k)
+        else:
+            assert_close(got[k], ref[k], tag + k)
+    # bounds are min/max of the kernel's own positions: must equal them exactly
+    p = got["position"]
+    assert_equal(got["aabb"][:, 0], p.min(axis=1), tag + "aabb.min")
+    assert_equal(got["aabb"][:, 1], p.max(axis=1), tag + "aabb.max")
+    if exact_skin:
+        assert_equal(got["aabb"], ref["aabb"], tag + "aabb")
+    else:
+        assert_close(got["aabb"], ref["aabb"], tag + "aabb")
+
+
+@pytest.mark.parametrize("pose_path", [1, 2])
+@pytest.mark.parametrize("exact", [1, 0])
+def test_tiny_rig_all_features(oracle32, pose_path, exact):
+    spec = synth.tiny_spec(matrix_nodes=1)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=7, with_root=True)
+    got = run_gpu(rig, crowd, pose_path=pose_path, exact_arithmetic=exact)
+    ref = run_oracle(oracle32, rig, crowd)
+    _check_all(got, ref, exact_pose=True, exact_skin=bool(exact))
+
+
+@pytest.mark.parametrize("quirk", [1, 0])
+def test_cubic_quirk_switch(oracle32, quirk):
+    spec = synth.tiny_spec(seed=11, frac_cubic=1.0, frac_step=0.0, keys=5)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=16)
+    got = run_gpu(rig, crowd, cubic_quirk=quirk, exact_arithmetic=1)
+    ref = run_oracle(oracle32, rig, crowd, cubic_quirk=quirk)
+    _check_all(got, ref, exact_skin=True)
+    other = run_oracle(oracle32, rig, crowd, cubic_quirk=1 - quirk, want=("world",))
+    assert not np.array_equal(other["world"], ref["world"]), "quirk switch must change CUBICSPLINE results"
+
+
+def test_normalized_outputs(oracle32):
+    spec = synth.tiny_spec(seed=3)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=4)
+    got = run_gpu(rig, crowd, normalize_outputs=1, exact_arithmetic=1)
+    ref = run_oracle(oracle32, rig, crowd, normalize_outputs=1)
+    _check_all(got, ref, exact_skin=True)
+    assert_close(np.linalg.norm(got["normal"], axis=2), np.ones((4, rig.vertex_count)), "unit normals", rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,inst", [("c1", 1), ("c2", 64), ("c3", 6)])
+@pytest.mark.parametrize("exact", [1, 0])
+def test_config_shapes(oracle32, name, inst, exact):
+    spec = synth.CONFIGS[name]
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=inst)
+    got = run_gpu(rig, crowd, exact_arithmetic=exact)
+    ref = run_oracle(oracle32, rig, crowd)
+    _check_all(got, ref, exact_skin=bool(exact), tag=name + ":")
+
+
+@pytest.mark.parametrize("exact", [1, 0])
+def test_c5_shape_reduced(oracle32, exact):
+    """C5's features at a size the oracle finishes in seconds: deep chain (split pose path chosen
+    automatically), 8 weights/vertex, compacted (sparse) morph targets."""
+    spec = synth.scaled(synth.CONFIGS["c5"], nodes=1500, joints=1500, verts=20000, targets=16, instances=3)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=3)
+    got = run_gpu(rig, crowd, exact_arithmetic=exact)
+    ref = run_oracle(oracle32, rig, crowd)
+    _check_all(got, ref, exact_skin=bool(exact), tag="c5r:")
+
+
+def test_scattered_joints_use_global_palette_path(oracle32):
+    """Worst-case locality: influences uniform over 300 joints -> tile joint lists exceed the LDS
+    cap and the kernel gathers the palette from L2 instead.  Joint gathers must stay exact."""
+    spec = synth.scaled(synth.tiny_spec(seed=5), nodes=320, joints=300, verts=1000, scatter_joints=True, targets=2, max_depth=10)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=5)
+    got = run_gpu(rig, crowd, exact_arithmetic=1)
+    assert got["info"].lds_tiles < got["info"].tile_count
+    ref = run_oracle(oracle32, rig, crowd)
+    _check_all(got, ref, exact_skin=True)
+
+
+def test_edge_cases(oracle32):
+    # no clips at all, no morph targets, one vertex, one joint
+    rig = abi.RigData(parent=[-1], translation=[[1, 2, 3]], rotation=[[0, 0, 0, 1]], scale=[[1, 1, 1]],
+                      joint_node=[0], position=[[1, 0, 0]], normal=[[0, 1, 0]], tangent=[[0, 0, 1, 1]],
+                      joints=[np.zeros((1, 4), np.uint16)], weights=[np.array([[1, 0, 0, 0]], np.float32)])
+    crowd = synth.CrowdState(tau=np.zeros(3, np.float32), clip_id=np.zeros(3, np.uint32), morph_weights=None)
+    got = run_gpu(rig, crowd, exact_arithmetic=1)
+    ref = run_oracle(oracle32, rig, crowd)
+    _check_all(got, ref, exact_skin=True)
+    assert_equal(got["position"][0, 0], np.array([2, 2, 3], np.float32), "rigid translate")
+
+    # rest pose via NO_CLIP, and out-of-window clocks (clamp to first/last key)
+    spec = synth.tiny_spec(seed=9)
+    rig = synth.make_rig(spec)
+    n = 6
+    crowd = synth.make_crowd(spec, rig, instances=n)
+    crowd.clip_id[:2] = abi.NO_CLIP
+    crowd.tau[2] = -5.0
+    crowd.tau[3] = 1e9
+    crowd.tau[4] = 0.0
+    got = run_gpu(rig, crowd, exact_arithmetic=1)
+    ref = run_oracle(oracle32, rig, crowd)
+    _check_all(got, ref, exact_skin=True)
+    assert (got["key_index"][:2] == 0xFFFFFFFF).all()
+
+
+def test_default_morph_weights_and_reset(oracle32):
+    spec = synth.tiny_spec(seed=21)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=4)
+    ctx = api.Context(exact_arithmetic=1)
+    r = api.Rig(ctx, rig)
+    c = api.Crowd(ctx, r, 4)
+    c.set_clocks(crowd.tau, crowd.clip_id)
+    c.evaluate(sync=True)                      # rig defaults
+    ref = oracle32.evaluate(rig, crowd.tau, crowd.clip_id, None, want=("position",))
+    assert_equal(c.positions(), ref.position, "default morph weights")
+    c.set_morph_weights(crowd.morph_weights)
+    c.evaluate(sync=True)
+    ref2 = oracle32.evaluate(rig, crowd.tau, crowd.clip_id, crowd.morph_weights, want=("position",))
+    assert_equal(c.positions(), ref2.position, "explicit morph weights")
+    c.set_morph_weights(None)
+    c.evaluate(sync=True)
+    assert_equal(c.positions(), ref.position, "weights reset to defaults")
+    c.close(); r.close(); ctx.close()
+
+
+def test_reference_layout_exports(oracle32):
+    spec = synth.tiny_spec(seed=2)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=3)
+    ctx = api.Context(exact_arithmetic=1)
+    r = api.Rig(ctx, rig)
+    c = api.Crowd(ctx, r, 3)
+    c.set_clocks(crowd.tau, crowd.clip_id)
+    c.set_morph_weights(crowd.morph_weights)
+    c.evaluate(sync=True)
+    ref = oracle32.evaluate(rig, crowd.tau, crowd.clip_id, crowd.morph_weights)
+    # SkinMatrix x 128, zero padded (uniform/skin.rs:41-50)
+    su = c.skin_uniform(1)
+    J = rig.joint_count
+    assert su.shape == (128, 28)
+    assert_equal(su[:J], ref.palette[1], "SkinMatrix entries")
+    assert (su[J:] == 0).all()
+    # TextureSkinVertex 60 B / ColorSkinVertex 68 B (buffer/vertex.rs:60-102)
+    V = rig.vertex_count
+    uv = np.arange(V * 2, dtype=np.float32).reshape(V, 2)
+    tv = c.interleaved(1, abi.LAYOUT_TEXTURE_SKIN, uv).reshape(V, 60)
+    f = tv[:, :44].copy().view(np.float32).reshape(V, 11)
+    assert_equal(f[:, 0:3], ref.position[1], "TextureSkinVertex.position")
+    assert_equal(f[:, 3:5], uv, "TextureSkinVertex.tex_coords")
+    assert_equal(f[:, 5:8], ref.normal[1], "TextureSkinVertex.normal")
+    assert_equal(f[:, 8:11], ref.tangent[1], "TextureSkinVertex.tangent")
+    assert_equal(tv[:, 44:52].copy().view(np.uint16).reshape(V, 4), rig.joints[0], "joint_index")
+    assert_equal(tv[:, 52:60].copy().view(np.float32).reshape(V, 4), rig.weights[0], "joint_weight")
+    cv = c.interleaved(2, abi.LAYOUT_COLOR_SKIN, None).reshape(V, 68)
+    g = cv[:, :52].copy().view(np.float32).reshape(V, 13)
+    assert_equal(g[:, 0:3], ref.position[2], "ColorSkinVertex.position")
+    assert (g[:, 3:7] == 0).all()
+    assert_equal(g[:, 7:10], ref.normal[2], "ColorSkinVertex.normal")
+    c.close(); r.close(); ctx.close()
+
+
+def test_error_behaviour_on_device():
+    spec = synth.tiny_spec()
+    rig = synth.make_rig(spec)
+    ctx = api.Context()
+    r = api.Rig(ctx, rig)
+    with pytest.raises(api.SkinrtError) as e:
+        api.Crowd(ctx, r, 0)
+    assert e.value.code == abi.E_INVALID
+    c = api.Crowd(ctx, r, 2)
+    with pytest.raises(api.SkinrtError) as e:
+        c.set_clocks(np.zeros(2, np.float32), np.array([0, 99], np.uint32))
+    assert e.value.code == abi.E_RANGE
+    bad = np.tile(np.eye(4, dtype=np.float32).reshape(1, 16), (2, 1)); bad[1, 3] = 0.5
+    with pytest.raises(api.SkinrtError) as e:
+        c.set_root_transforms(bad)
+    assert e.value.code == abi.E_NONAFFINE
+    with pytest.raises(api.SkinrtError) as e:
+        c.evaluate(abi.STAGE_AABB)
+    assert e.value.code == abi.E_INVALID
+    with pytest.raises(api.SkinrtError):
+        api.Context(device=4096)
+    c.close(); r.close(); ctx.close()
