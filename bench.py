@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — skinned vertices/s of the per-frame skinned-scene evaluation path on MI355X.
+
+A "step" is one frame of the hot path over the rank's crowd shard: animation sampling ->
+hierarchy propagation -> joint palette -> morph + linear-blend skinning -> per-instance bounds
+(skinrt_evaluate(STAGE_ALL)), plus, for N > 1, the RCCL all-gather of the bounds.  Inputs
+(rig tables, clocks, morph weights) are resident in HBM before the timed region.
+
+Workload: N=1 -> BASELINE.json configs[2] (C3: VRM-shaped avatar, 60k verts, 200 joints,
+4 weights, 32 morph targets x 10,000 instances — the config the roofline target is quoted on);
+N>1 -> configs[3] (C4: the same avatar x 100,000 instances sharded over the N GPUs).
+`--workload c2|c5` benches the other single-GPU configs.  Synthetic rigs (renderer_amd/synth.py).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from renderer_amd import abi, api, shard, synth  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(rig, instances):
+    """B = I*V*36 + I*(J*84 + 4*M) + V*(36 + 24*K) + D, D = dense M*V*36 or
+    sparse sum nnz*(4+36).  Shared mesh / morph data counted once per frame."""
+    V, J, M, K = rig.vertex_count, rig.joint_count, rig.target_count, rig.set_count
+    d = 0
+    for t in rig.targets:
+        d += V * 36 if t.indices is None else int(t.indices.shape[0]) * 40
+    return instances * V * 36 + instances * (J * 84 + 4 * M) + V * (36 + 24 * K) + d
+
+
+def cpu_baseline(rig, spec, budget_s=12.0):
+    """Oracle (fp32 C restatement, reference op order, -O2 -ffp-contract=off) timed on this
+    box's host cores on a bounded sample of the same workload: single thread (the reference has
+    one render thread, renderer/src/state.rs:236), then instance-parallel over 16 threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.oracle import Oracle, OracleResult
+
+    orc = Oracle("f32")
+    V = rig.vertex_count
+    want = ("palette", "position", "normal", "tangent", "aabb")
+    probe = synth.make_crowd(spec, rig, instances=2)
+    desc = rig.to_desc()
+    t0 = time.perf_counter()
+    orc.evaluate(rig, probe.tau, probe.clip_id, probe.morph_weights, want=want, desc=desc)
+    per_inst = max((time.perf_counter() - t0) / 2, 1e-6)
+    n = int(max(2, min(spec.instances, budget_s / per_inst, 2.0e9 / (V * 36 + 1))))
+    crowd = synth.make_crowd(spec, rig, instances=n)
+    res = OracleResult()
+    t0 = time.perf_counter()
+    orc.evaluate(rig, crowd.tau, crowd.clip_id, crowd.morph_weights, want=want, desc=desc, into=res)
+    dt1 = time.perf_counter() - t0
+    threads = 16
+    chunks = [(k * n // threads, (k + 1) * n // threads) for k in range(threads)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda c: orc.evaluate(rig, crowd.tau, crowd.clip_id, crowd.morph_weights, want=want,
+                                           desc=desc, into=res, begin=c[0], end=c[1]), chunks))
+    dtm = time.perf_counter() - t0
+    sample = f"{rig.name} rig ({V} verts) x {n} of {spec.instances} instances, all stages, one frame"
+    one = {"value": n * V / dt1, "unit": "skinned vertices/s", "cores": 1, "kind": "port", "sample": sample,
+           "seconds": round(dt1, 3)}
+    many = {"value": n * V / dtm, "unit": "skinned vertices/s", "cores": threads, "kind": "port", "sample": sample,
+            "seconds": round(dtm, 3), "host_cpus": os.cpu_count()}
+    return one, many
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=[None, "c2", "c3", "c4", "c5"])
+    ap.add_argument("--instances", type=int, default=None, help="override the TOTAL instance count")
+    ap.add_argument("--gather-vertices", action="store_true", help="also all-gather position buffers (xGMI-bound)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact", type=int, default=0, help="1: contraction-free skinning kernel (bit-equal to the oracle)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = max(args.gpus, world)
+
+    name = args.workload or ("c3" if n_gpus == 1 else "c4")
+    spec = synth.CONFIGS[name]
+    total = args.instances or spec.instances
+    lo, hi = shard.shard_range(total, rank, world)
+    mine = hi - lo
+    rig_data = synth.make_rig(spec)
+    crowd_in = synth.make_crowd(spec, rig_data, instances=mine, first=lo)
+
+    ctx = api.Context(device=local_rank, exact_arithmetic=args.exact)
+    rig = api.Rig(ctx, rig_data)
+    crowd = api.Crowd(ctx, rig, mine)
+    crowd.set_clocks(crowd_in.tau, crowd_in.clip_id)
+    if crowd_in.morph_weights is not None:
+        crowd.set_morph_weights(crowd_in.morph_weights)
+    V = rig_data.vertex_count
+
+    aabb_t = pos_t = None
+    if world > 1:
+        ptr, _ = crowd.device_pointer("aabbs")
+        aabb_t = torch.as_tensor(shard.DeviceArray(ptr, (mine, 6)), device=f"cuda:{local_rank}")
+        if args.gather_vertices:
+            pptr, _ = crowd.device_pointer("positions")
+            pos_t = torch.as_tensor(shard.DeviceArray(pptr, (mine, V * 3)), device=f"cuda:{local_rank}")
+
+    def step():
+        crowd.evaluate(abi.STAGE_ALL)
+        if world > 1:
+            ctx.synchronize()  # the library's stream -> torch's stream hand-off
+            shard.all_gather_rows(aabb_t, total, world)
+            if pos_t is not None:
+                shard.all_gather_rows(pos_t, total, world)
+
+    def fence():
+        ctx.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    stage = np.zeros((args.steps, 4))
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step()
+        stage[k] = crowd.stage_ms()  # HIP events on the library's stream, around each kernel
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = total * V * args.steps / dt
+        skin_ms = float(stage[:, 1].mean())
+        bytes_launch = algorithmic_bytes(rig_data, mine)
+        achieved = bytes_launch / (skin_ms * 1e-3)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{name}:{mine}")
+            except Exception:
+                traffic = None
+        info = rig.info
+        out = {
+            "metric": "skinned vertices/sec (whole node) + ms/frame at N avatars; % HBM roofline",
+            "value": value, "unit": "skinned vertices/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if n_gpus == 1 else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}: VRM-shaped avatar x instances" if name in ("c3", "c4") else name,
+                       "instances_total": total, "instances_per_gpu": mine, "vertices": V,
+                       "joints": rig_data.joint_count, "nodes": rig_data.node_count, "weight_sets": rig_data.set_count,
+                       "morph_targets": rig_data.target_count, "channels": rig_data.max_channels,
+                       "stages": "pose+morph+skin+aabb" + ("+allgather(aabb)" if world > 1 else "") +
+                                 ("+allgather(positions)" if args.gather_vertices and world > 1 else ""),
+                       "exact_arithmetic": args.exact, "parallelism": f"instances sharded x{n_gpus}"},
+            "stage_ms": {"pose": float(stage[:, 0].mean()), "skin_morph": skin_ms,
+                         "aabb_reduce": float(stage[:, 2].mean()), "device_span": float(stage[:, 3].mean())},
+            "roofline": {"bound": "hbm", "kernel": "k_skin (morph + linear-blend skinning)", "achieved": achieved / 1e9,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": skin_ms, "traffic": traffic},
+            "rig_compile": {"tiles": info.tile_count, "max_tile_joints": info.max_tile_joints,
+                            "lds_tiles": info.lds_tiles, "morph_entries": int(info.morph_entries)},
+        }
+        if not args.no_cpu_baseline and n_gpus == 1:
+            one, many = cpu_baseline(rig_data, spec)
+            out["cpu_baseline"] = one
+            out["cpu_baseline_mt"] = many
+        print(json.dumps(out), flush=True)
+
+    crowd.close(); rig.close(); ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
