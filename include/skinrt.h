@@ -61,8 +61,8 @@ extern "C" {
 #define SKINRT_STAGE_ALL 7u
 
 /* vertex layouts of skinrt_export_interleaved — renderer/src/renderer/buffer/vertex.rs */
-#define SKINRT_LAYOUT_COLOR_SKIN 0    /* ColorSkinVertex, 68 B  (:60-69) */
-#define SKINRT_LAYOUT_TEXTURE_SKIN 1  /* TextureSkinVertex, 60 B (:82-91) */
+#define SKINRT_LAYOUT_COLOR_SKIN 0    /* ColorSkinVertex, 76 B  (:60-69) */
+#define SKINRT_LAYOUT_TEXTURE_SKIN 1  /* TextureSkinVertex, 68 B (:82-91) */
 
 #define SKINRT_MAX_JOINTS_REFERENCE 128 /* MAX_JOINTS, renderer/src/renderer/uniform/skin.rs:10 */
 #define SKINRT_SKIN_MATRIX_BYTES 112    /* SkinMatrix{[[f32;4];4],[[f32;4];3]}, uniform/skin.rs:12-17 */
@@ -262,7 +262,7 @@ SKINRT_API int skinrt_download(skinrt_ctx* ctx, const void* dev_src, void* host_
  * column-major, then 3 x vec4 normal columns padded with 0), entries >= J zero
  * (uniform/skin.rs:41-50; shader.wgsl:70-77).  Requires J <= 128. dst: 14336 bytes. */
 SKINRT_API int skinrt_export_skin_uniform(skinrt_crowd* crowd, uint32_t instance, void* dst);
-/* One instance's vertices in ColorSkinVertex (68 B) or TextureSkinVertex (60 B) layout
+/* One instance's vertices in ColorSkinVertex (76 B) or TextureSkinVertex (68 B) layout
  * (buffer/vertex.rs:60-102): position/normal/tangent = skinned outputs; joint_index /
  * joint_weight = the rig's set-0 indices/weights passed through unchanged; color (4 f32) or
  * tex_coords (2 f32) are copied from `attr` ([V][4] or [V][2], NULL = zeros). dst: V*stride bytes. */

@@ -260,7 +260,7 @@ class Crowd:
         return out
 
     def interleaved(self, instance: int, layout: int, attr=None) -> np.ndarray:
-        stride = 68 if layout == abi.LAYOUT_COLOR_SKIN else 60
+        stride = 76 if layout == abi.LAYOUT_COLOR_SKIN else 68
         out = np.empty(self.rig.data.vertex_count * stride, dtype=np.uint8)
         ap = None
         if attr is not None:

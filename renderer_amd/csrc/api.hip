@@ -110,10 +110,13 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
     SkinPlan p{};
     p.jt_shift = ceil_log2(std::max<uint32_t>(1, r.max_tile_joints));
     const uint32_t JTP = 1u << p.jt_shift;
-    const uint32_t per_inst = JTP * 96 + r.M * 4 + 16 * 6 * 4;
-    const uint32_t budget = 40 * 1024;
+    p.max_pairs = r.max_tile_pairs;
+    p.lds_tiles = r.lds_tiles;
+    // per instance: palette rows, morph weights, bounds partials, active-pair list (+ count)
+    const uint32_t per_inst = JTP * 96 + r.M * 4 + 16 * 6 * 4 + (p.max_pairs + 1) * 4;
+    const uint32_t budget = 24 * 1024;
     p.batch = std::min<uint32_t>(16, std::max<uint32_t>(1, budget / per_inst));
-    p.lds_bytes = p.batch * per_inst;
+    p.lds_bytes = p.batch * per_inst + p.max_pairs * 16;
     // enough blocks to fill 256 CUs several times over, but ranges long enough to amortise the
     // per-block vertex load
     const uint64_t want_blocks = 4096;
@@ -219,7 +222,7 @@ int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig**
 #define UP(field) if ((rc = upload(r, h.field, &d.field)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
     UP(parent) UP(rest_trs) UP(rest_mat) UP(node_matrix) UP(level_start) UP(level_nodes) UP(node_chan)
     UP(chans) UP(clip_chan_count) UP(times) UP(values) UP(joint_node) UP(ibm) UP(base) UP(wts) UP(lidx)
-    UP(tile_joint_start) UP(tile_joints) UP(tile_lds) UP(mptr) UP(mtgt) UP(mdelta)
+    UP(tile_joint_start) UP(tile_joints) UP(tile_lds) UP(tile_pair_start) UP(pairs) UP(mblock) UP(mmap)
 #undef UP
     if ((rc = upload(r, h.default_weights, &defw)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
     r->default_mw = r->bufs.back();
@@ -301,7 +304,7 @@ int skinrt_set_clocks(skinrt_crowd* c, const float* tau, const uint32_t* clip_id
     if (int rc = check_crowd(c)) return rc;
     if (!tau) return fail(SKINRT_E_INVALID, "tau is NULL");
     HIP_TRY(hipSetDevice(c->ctx->cfg.device));
-    if (clip_id)
+    if (clip_id && c->rig->host.clips)  // a rig without animations is always at rest, whatever the id
         for (uint32_t i = 0; i < c->I; ++i)
             if (clip_id[i] != UINT32_MAX && clip_id[i] >= c->rig->host.clips)
                 return fail(SKINRT_E_RANGE, "clip_id out of range");
@@ -444,7 +447,7 @@ int skinrt_export_interleaved(skinrt_crowd* c, uint32_t instance, uint32_t layou
     if (int rc = skinrt_download(c->ctx, c->nrm.as<float>() + off, n.data(), V * 12)) return rc;
     if (int rc = skinrt_download(c->ctx, c->tan.as<float>() + off, t.data(), V * 12)) return rc;
     const uint32_t na = layout == SKINRT_LAYOUT_COLOR_SKIN ? 4 : 2;
-    const size_t stride = layout == SKINRT_LAYOUT_COLOR_SKIN ? 68 : 60;
+    const size_t stride = layout == SKINRT_LAYOUT_COLOR_SKIN ? 76 : 68;
     uint8_t* o = static_cast<uint8_t*>(dst);
     for (size_t v = 0; v < V; ++v, o += stride) {
         uint8_t* q = o;

@@ -30,9 +30,10 @@ struct RigDev {
     const uint32_t* tile_joint_start;
     const uint32_t* tile_joints;
     const uint8_t* tile_lds;
-    const uint32_t* mptr;
-    const uint16_t* mtgt;
-    const float* mdelta;
+    const uint32_t* tile_pair_start;
+    const MorphPair* pairs;
+    const float* mblock;
+    const uint8_t* mmap;
 };
 
 // Per-crowd state and outputs (HBM layout: DESIGN.md §3).
@@ -58,6 +59,8 @@ struct SkinPlan {
     uint32_t ranges;    // ceil(I / range)
     uint32_t batch;     // instances whose palettes are LDS-resident at once
     uint32_t jt_shift;  // log2 of the padded tile joint-list length
+    uint32_t lds_tiles; // tiles whose joint list is LDS-staged (the rest gather from L2)
+    uint32_t max_pairs; // largest number of (tile, target) morph pairs in one tile
     uint32_t lds_bytes; // dynamic LDS per block
     uint32_t exact;     // 1: contraction-free arithmetic (bit-equal to the fp32 oracle)
     uint32_t normalize; // shader.wgsl:217-218 variant

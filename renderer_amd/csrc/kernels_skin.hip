@@ -67,28 +67,20 @@ struct GlobalPal {
     __device__ __forceinline__ const float4* entry(uint32_t idx) const { return base + idx * 6; }
 };
 
+// Position pass then normal/tangent pass: the two accumulators (12 + 9 floats) are never live
+// together, and each influence's rows are consumed right after they arrive, which keeps the
+// kernel at <= 96 VGPRs (5 waves per SIMD) so other waves cover the LDS latency.
 template <bool EXACT, int K, class Pal>
-__device__ __forceinline__ void skin_one(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
-                                         const float p[3], const float n[3], const float t[3], bool normalize,
-                                         float op[3], float on[3], float ot[3]) {
-    float S[12], Nm[9];
+__device__ __forceinline__ void skin_position(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
+                                              const float p[3], float op[3]) {
+    float S[12];
 #pragma unroll
     for (int a = 0; a < 4 * K; ++a) {
         const float4* e = pal.entry(li[a]);
-        const float4 r0 = e[0], r1 = e[1], r2 = e[2], n0 = e[3], n1 = e[4], n2 = e[5];
+        const float4 r0 = e[0], r1 = e[1], r2 = e[2];
         const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-        const float q[9] = {n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, n2.x, n2.y, n2.z};
-        if (a == 0) {
 #pragma unroll
-            for (int x = 0; x < 12; ++x) S[x] = mul<EXACT>(w[0], m[x]);
-#pragma unroll
-            for (int x = 0; x < 9; ++x) Nm[x] = mul<EXACT>(w[0], q[x]);
-        } else {
-#pragma unroll
-            for (int x = 0; x < 12; ++x) S[x] = madd<EXACT>(w[a], m[x], S[x]);
-#pragma unroll
-            for (int x = 0; x < 9; ++x) Nm[x] = madd<EXACT>(w[a], q[x], Nm[x]);
-        }
+        for (int x = 0; x < 12; ++x) S[x] = a == 0 ? mul<EXACT>(w[0], m[x]) : madd<EXACT>(w[a], m[x], S[x]);
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -96,6 +88,23 @@ __device__ __forceinline__ void skin_one(const Pal pal, const float (&w)[4 * K],
         s = madd<EXACT>(S[r * 4 + 1], p[1], s);
         s = madd<EXACT>(S[r * 4 + 2], p[2], s);
         op[r] = add_nc(s, S[r * 4 + 3]);
+    }
+}
+
+template <bool EXACT, int K, class Pal>
+__device__ __forceinline__ void skin_normal(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
+                                            const float n[3], const float t[3], bool normalize, float on[3], float ot[3]) {
+    float Nm[9];
+#pragma unroll
+    for (int a = 0; a < 4 * K; ++a) {
+        const float4* e = pal.entry(li[a]);
+        const float4 n0 = e[3], n1 = e[4], n2 = e[5];
+        const float q[9] = {n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, n2.x, n2.y, n2.z};
+#pragma unroll
+        for (int x = 0; x < 9; ++x) Nm[x] = a == 0 ? mul<EXACT>(w[0], q[x]) : madd<EXACT>(w[a], q[x], Nm[x]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
         float a = mul<EXACT>(Nm[r * 3 + 0], n[0]);
         a = madd<EXACT>(Nm[r * 3 + 1], n[1], a);
         on[r] = madd<EXACT>(Nm[r * 3 + 2], n[2], a);
@@ -111,8 +120,18 @@ __device__ __forceinline__ void skin_one(const Pal pal, const float (&w)[4 * K],
     }
 }
 
-template <bool EXACT, int K>
-__global__ __launch_bounds__(256, 2) void k_skin(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
+template <bool EXACT>
+__device__ __forceinline__ void morph_add(float mw, const float d[9], float p[3], float n[3], float t[3]) {
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        p[x] = madd<EXACT>(mw, d[x], p[x]);
+        n[x] = madd<EXACT>(mw, d[3 + x], n[x]);
+        t[x] = madd<EXACT>(mw, d[6 + x], t[x]);
+    }
+}
+
+template <bool EXACT, int K, bool LDSPAL>
+__global__ __launch_bounds__(256, (K == 1 ? 4 : 2)) void k_skin(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
@@ -124,9 +143,12 @@ __global__ __launch_bounds__(256, 2) void k_skin(const RigDev rig, const CrowdDe
     const uint32_t JTP = 1u << plan.jt_shift;
     const uint32_t B = plan.batch;
     const uint32_t M = rig.M;
-    float4* pal_s = smem;                                            // [B][JTP][6]
-    float* mw_s = reinterpret_cast<float*>(pal_s + (size_t)B * JTP * 6);  // [B][M]
-    float* ab_s = mw_s + (size_t)B * M;                              // [B][16][6]
+    const uint32_t P1 = plan.max_pairs + 1;
+    float4* pal_s = smem;                                                 // [B][JTP][6]
+    MorphPair* pairs_s = reinterpret_cast<MorphPair*>(pal_s + (size_t)B * JTP * 6);  // [max_pairs]
+    float* mw_s = reinterpret_cast<float*>(pairs_s + plan.max_pairs);     // [B][M]
+    float* ab_s = mw_s + (size_t)B * M;                                   // [B][16][6]
+    uint32_t* act_s = reinterpret_cast<uint32_t*>(ab_s + (size_t)B * 16 * 6);  // [B][1 + max_pairs]
 
     // ---- this thread's vertex ------------------------------------------------------------
     const uint32_t v = tile * TV + tid;
@@ -142,8 +164,13 @@ __global__ __launch_bounds__(256, 2) void k_skin(const RigDev rig, const CrowdDe
 #pragma unroll
         for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
     }
-    const uint32_t mbeg = rig.mptr[v], mend = rig.mptr[v + 1];
-    const bool lds_tile = rig.tile_lds[tile] != 0;
+    // morph: this tile's (tile, target) pairs; their records live in LDS for the whole block
+    const uint32_t pbeg = rig.tile_pair_start[tile];
+    const uint32_t np = rig.tile_pair_start[tile + 1] - pbeg;
+    for (uint32_t c = tid; c < np; c += 256) pairs_s[c] = rig.pairs[pbeg + c];
+    // tiles whose joint list fits LDS are skinned by the LDSPAL=true launch, the rest (rare: no
+    // joint locality) by the LDSPAL=false launch that gathers the palette from L2
+    if ((rig.tile_lds[tile] != 0) != LDSPAL) return;
     const uint32_t jstart = rig.tile_joint_start[tile];
     const uint32_t jcnt = rig.tile_joint_start[tile + 1] - jstart;
     const float4* pal_g = reinterpret_cast<const float4*>(cr.palette);
@@ -151,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void k_skin(const RigDev rig, const CrowdDe
 
     for (uint32_t ib = i0; ib < i1; ib += B) {
         const uint32_t nb = min(B, i1 - ib);
-        __syncthreads();  // previous batch's readers are done with LDS
-        if (lds_tile) {
+        __syncthreads();  // previous batch's readers are done with LDS (and pairs_s is visible)
+        if (LDSPAL) {
             const uint32_t chunks = (nb << plan.jt_shift) * 6;
             for (uint32_t c = tid; c < chunks; c += 256) {
                 const uint32_t row = c / 6, q = c - row * 6;
@@ -164,30 +191,59 @@ __global__ __launch_bounds__(256, 2) void k_skin(const RigDev rig, const CrowdDe
             }
         }
         for (uint32_t c = tid; c < nb * M; c += 256) mw_s[c] = cr.mw[(size_t)ib * M + c];
+        // per instance: which of the tile's pairs have a non-zero weight (zero weights add exactly 0)
+        if (tid < nb) {
+            uint32_t* act = act_s + tid * P1;
+            const float* mwg = cr.mw + (size_t)(ib + tid) * M;
+            uint32_t n = 0;
+            for (uint32_t q = 0; q < np; ++q)
+                if (mwg[pairs_s[q].target] != 0.0f) act[++n] = q;
+            act[0] = n;
+        }
         __syncthreads();
 
         for (uint32_t b = 0; b < nb; ++b) {
             const uint32_t i = ib + b;
             float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
-            // a13: p = p0 + sum_m w_m * delta_m, targets ascending; zero weights add exactly 0
-            for (uint32_t e = mbeg; e < mend; ++e) {
-                const float mw = mw_s[b * M + rig.mtgt[e]];
-                if (mw != 0.0f) {
-                    const float* d = rig.mdelta + (size_t)e * 9;
+            // a13: p = p0 + sum_m w_m * delta_m, targets ascending (wave-uniform loop)
+            const uint32_t* act = act_s + b * P1;
+            const uint32_t na = __builtin_amdgcn_readfirstlane(act[0]);
+            for (uint32_t a = 1; a <= na; ++a) {
+                const uint32_t q = __builtin_amdgcn_readfirstlane(act[a]);
+                const MorphPair mp = pairs_s[q];
+                const uint32_t doff = __builtin_amdgcn_readfirstlane(mp.data_off);
+                const float mw = mw_s[b * M + __builtin_amdgcn_readfirstlane((uint32_t)mp.target)];
+                if (__builtin_amdgcn_readfirstlane(mp.dense)) {
+                    const float* blk = rig.mblock + doff + tid;
+                    float d[9];
 #pragma unroll
-                    for (int x = 0; x < 3; ++x) {
-                        p[x] = madd<EXACT>(mw, d[x], p[x]);
-                        n[x] = madd<EXACT>(mw, d[3 + x], n[x]);
-                        t[x] = madd<EXACT>(mw, d[6 + x], t[x]);
+                    for (int x = 0; x < 9; ++x) d[x] = blk[x * TV];
+                    morph_add<EXACT>(mw, d, p, n, t);
+                } else {
+                    const uint32_t slot = rig.mmap[__builtin_amdgcn_readfirstlane(mp.map_off) + tid];
+                    if (slot) {
+                        const float* dp = rig.mblock + doff + (slot - 1) * 9;
+                        float d[9];
+#pragma unroll
+                        for (int x = 0; x < 9; ++x) d[x] = dp[x];
+                        morph_add<EXACT>(mw, d, p, n, t);
                     }
                 }
             }
             float op[3], on[3], ot[3];
-            if (lds_tile) skin_one<EXACT, K>(LdsPal{pal_s + (size_t)b * JTP * 6}, w, li, p, n, t, plan.normalize != 0, op, on, ot);
-            else skin_one<EXACT, K>(GlobalPal{pal_g + (size_t)i * rig.J * 6}, w, li, p, n, t, plan.normalize != 0, op, on, ot);
+            const size_t o = ((size_t)i * rig.V + v) * 3;
+            if constexpr (LDSPAL) {
+                const LdsPal pal{pal_s + (size_t)b * JTP * 6};
+                skin_position<EXACT, K>(pal, w, li, p, op);
+                if (valid) *reinterpret_cast<float3*>(cr.pos + o) = make_float3(op[0], op[1], op[2]);
+                skin_normal<EXACT, K>(pal, w, li, n, t, plan.normalize != 0, on, ot);
+            } else {
+                const GlobalPal pal{pal_g + (size_t)i * rig.J * 6};
+                skin_position<EXACT, K>(pal, w, li, p, op);
+                if (valid) *reinterpret_cast<float3*>(cr.pos + o) = make_float3(op[0], op[1], op[2]);
+                skin_normal<EXACT, K>(pal, w, li, n, t, plan.normalize != 0, on, ot);
+            }
             if (valid) {
-                const size_t o = ((size_t)i * rig.V + v) * 3;
-                *reinterpret_cast<float3*>(cr.pos + o) = make_float3(op[0], op[1], op[2]);
                 *reinterpret_cast<float3*>(cr.nrm + o) = make_float3(on[0], on[1], on[2]);
                 *reinterpret_cast<float3*>(cr.tan + o) = make_float3(ot[0], ot[1], ot[2]);
             }
@@ -235,14 +291,14 @@ __global__ __launch_bounds__(256) void k_fill_mw(float* mw, const float* default
     if (g < total) mw[g] = defaults[g % M];
 }
 
-template <bool EXACT>
+template <bool EXACT, bool LDSPAL>
 hipError_t launch_skin_k(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s) {
     const dim3 grid(rig.T * plan.ranges), block(256);
     switch (rig.K) {
-        case 1: hipLaunchKernelGGL((k_skin<EXACT, 1>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
-        case 2: hipLaunchKernelGGL((k_skin<EXACT, 2>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
-        case 3: hipLaunchKernelGGL((k_skin<EXACT, 3>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
-        case 4: hipLaunchKernelGGL((k_skin<EXACT, 4>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
+        case 1: hipLaunchKernelGGL((k_skin<EXACT, 1, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
+        case 2: hipLaunchKernelGGL((k_skin<EXACT, 2, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
+        case 3: hipLaunchKernelGGL((k_skin<EXACT, 3, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
+        case 4: hipLaunchKernelGGL((k_skin<EXACT, 4, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -252,7 +308,12 @@ hipError_t launch_skin_k(const RigDev& rig, const CrowdDev& cr, const SkinPlan& 
 
 hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s) {
     if (cr.I == 0 || rig.T == 0) return hipSuccess;
-    return plan.exact ? launch_skin_k<true>(rig, cr, plan, s) : launch_skin_k<false>(rig, cr, plan, s);
+    hipError_t e = hipSuccess;
+    if (plan.lds_tiles)
+        e = plan.exact ? launch_skin_k<true, true>(rig, cr, plan, s) : launch_skin_k<false, true>(rig, cr, plan, s);
+    if (e == hipSuccess && plan.lds_tiles < rig.T)
+        e = plan.exact ? launch_skin_k<true, false>(rig, cr, plan, s) : launch_skin_k<false, false>(rig, cr, plan, s);
+    return e;
 }
 
 hipError_t launch_aabb_reduce(const RigDev& rig, const CrowdDev& cr, hipStream_t s) {

@@ -272,46 +272,73 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
     REQUIRE(M == 0 || d->targets, SKINRT_E_INVALID, "targets is NULL");
     r.default_weights.assign(M, 0.0f);
     if (d->default_weights) r.default_weights.assign(d->default_weights, d->default_weights + M);
-    r.mptr.assign((size_t)T * TV + 1, 0);
-    auto for_each_entry = [&](auto&& fn) {
-        for (uint32_t m = 0; m < M; ++m) {
-            const skinrt_morph_target_desc& tg = d->targets[m];
-            if (!tg.indices) REQUIRE(tg.count == V, SKINRT_E_INVALID, "dense morph target count != vertex_count");
-            uint32_t prev = 0;
-            for (uint32_t row = 0; row < tg.count; ++row) {
-                uint32_t v = tg.indices ? tg.indices[row] : row;
-                if (tg.indices) {
-                    REQUIRE(v < V, SKINRT_E_RANGE, "morph target vertex index out of range");
-                    REQUIRE(row == 0 || v > prev, SKINRT_E_INVALID, "morph target indices must be strictly increasing");
-                    prev = v;
-                }
-                float dl[9];
-                for (int e = 0; e < 3; ++e) {
-                    dl[e] = tg.position ? tg.position[(size_t)row * 3 + e] : 0.0f;
-                    dl[3 + e] = tg.normal ? tg.normal[(size_t)row * 3 + e] : 0.0f;
-                    dl[6 + e] = tg.tangent ? tg.tangent[(size_t)row * r.tangent_stride + e] : 0.0f;
-                }
-                bool nz = false;
-                for (int e = 0; e < 9; ++e) {
-                    REQUIRE(std::isfinite(dl[e]), SKINRT_E_INVALID, "non-finite morph delta");
-                    nz |= dl[e] != 0.0f;
-                }
-                if (nz) fn(v, m, dl);  // an all-zero delta adds exactly 0: dropped
-            }
-        }
+    // (tile, target) pairs: every target that moves at least one vertex of a tile gets one pair
+    // there, targets ascending inside a tile.  >= kMorphDenseMin touched vertices: a dense
+    // [9][256] SoA block (zeros elsewhere: w*0 adds exactly 0); fewer: a 256-byte slot map plus
+    // the touched vertices' deltas.
+    struct PairTmp {
+        uint32_t target;
+        std::vector<uint8_t> lv;
+        std::vector<float> dl;
     };
-    for_each_entry([&](uint32_t v, uint32_t, const float*) { r.mptr[v + 1]++; });
-    for (size_t v = 0; v < (size_t)T * TV; ++v) r.mptr[v + 1] += r.mptr[v];
-    const size_t E = r.mptr[(size_t)T * TV];
-    r.mtgt.resize(E);
-    r.mdelta.resize(E * 9);
-    {
-        std::vector<uint32_t> cur(r.mptr.begin(), r.mptr.end() - 1);
-        for_each_entry([&](uint32_t v, uint32_t m, const float* dl) {
-            const uint32_t e = cur[v]++;
-            r.mtgt[e] = (uint16_t)m;
-            std::memcpy(&r.mdelta[(size_t)e * 9], dl, 36);
-        });
+    std::vector<std::vector<PairTmp>> per_tile(T);
+    r.morph_entries = 0;
+    for (uint32_t m = 0; m < M; ++m) {
+        const skinrt_morph_target_desc& tg = d->targets[m];
+        if (!tg.indices) REQUIRE(tg.count == V, SKINRT_E_INVALID, "dense morph target count != vertex_count");
+        uint32_t prev = 0;
+        for (uint32_t row = 0; row < tg.count; ++row) {
+            const uint32_t v = tg.indices ? tg.indices[row] : row;
+            if (tg.indices) {
+                REQUIRE(v < V, SKINRT_E_RANGE, "morph target vertex index out of range");
+                REQUIRE(row == 0 || v > prev, SKINRT_E_INVALID, "morph target indices must be strictly increasing");
+                prev = v;
+            }
+            float dl[9];
+            for (int e = 0; e < 3; ++e) {
+                dl[e] = tg.position ? tg.position[(size_t)row * 3 + e] : 0.0f;
+                dl[3 + e] = tg.normal ? tg.normal[(size_t)row * 3 + e] : 0.0f;
+                dl[6 + e] = tg.tangent ? tg.tangent[(size_t)row * r.tangent_stride + e] : 0.0f;
+            }
+            bool nz = false;
+            for (int e = 0; e < 9; ++e) {
+                REQUIRE(std::isfinite(dl[e]), SKINRT_E_INVALID, "non-finite morph delta");
+                nz |= dl[e] != 0.0f;
+            }
+            if (!nz) continue;  // an all-zero delta adds exactly 0: dropped
+            std::vector<PairTmp>& tp = per_tile[v / TV];
+            if (tp.empty() || tp.back().target != m) tp.push_back(PairTmp{m, {}, {}});
+            tp.back().lv.push_back((uint8_t)(v % TV));
+            tp.back().dl.insert(tp.back().dl.end(), dl, dl + 9);
+            r.morph_entries++;
+        }
+    }
+    r.tile_pair_start.assign(T + 1, 0);
+    r.max_tile_pairs = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+        r.tile_pair_start[t + 1] = r.tile_pair_start[t] + (uint32_t)per_tile[t].size();
+        r.max_tile_pairs = std::max<uint32_t>(r.max_tile_pairs, (uint32_t)per_tile[t].size());
+        for (const PairTmp& pt : per_tile[t]) {
+            MorphPair mp{};
+            mp.target = (uint16_t)pt.target;
+            mp.cnt = (uint16_t)pt.lv.size();
+            mp.dense = pt.lv.size() >= kMorphDenseMin ? 1u : 0u;
+            mp.data_off = (uint32_t)r.mblock.size();
+            mp.map_off = (uint32_t)r.mmap.size();
+            if (mp.dense) {
+                r.mblock.resize(r.mblock.size() + 9 * TV, 0.0f);
+                float* blk = &r.mblock[mp.data_off];
+                for (size_t k = 0; k < pt.lv.size(); ++k)
+                    for (int e = 0; e < 9; ++e) blk[e * TV + pt.lv[k]] = pt.dl[k * 9 + e];
+            } else {
+                r.mmap.resize(r.mmap.size() + TV, 0);
+                for (size_t k = 0; k < pt.lv.size(); ++k) r.mmap[mp.map_off + pt.lv[k]] = (uint8_t)(k + 1);
+                r.mblock.insert(r.mblock.end(), pt.dl.begin(), pt.dl.end());
+            }
+            REQUIRE(r.mblock.size() < (1ull << 32), SKINRT_E_INVALID, "morph delta pool exceeds 2^32 floats");
+            r.pairs.push_back(mp);
+        }
+        std::vector<PairTmp>().swap(per_tile[t]);
     }
 }
 
@@ -333,7 +360,7 @@ void fill_rig_info(const CompiledRig& r, uint64_t device_bytes, skinrt_rig_info*
     info->node_count = r.N; info->joint_count = r.J; info->vertex_count = r.V; info->set_count = r.K;
     info->target_count = r.M; info->clip_count = r.clips; info->level_count = r.levels;
     info->tile_count = r.T; info->tile_vertices = kTileVerts; info->max_tile_joints = r.max_tile_joints_any;
-    info->lds_tiles = r.lds_tiles; info->max_channels = r.Cmax; info->morph_entries = r.mtgt.size();
+    info->lds_tiles = r.lds_tiles; info->max_channels = r.Cmax; info->morph_entries = r.morph_entries;
     info->device_bytes = device_bytes;
 }
 

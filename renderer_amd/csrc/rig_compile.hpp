@@ -23,6 +23,16 @@ struct ChanRec {
     uint8_t path;        // SKINRT_PATH_*
 };
 
+// one morph target's effect on one vertex tile
+struct MorphPair {
+    uint32_t data_off;  // into mblock[]: dense -> [9][256] SoA; sparse -> [cnt][9]
+    uint32_t map_off;   // into mmap[] (sparse only)
+    uint16_t target;
+    uint16_t cnt;       // touched vertices
+    uint32_t dense;
+};
+constexpr uint32_t kMorphDenseMin = 96;  // touched vertices from which a pair is stored dense
+
 struct CompiledRig {
     uint32_t N = 0, J = 0, V = 0, K = 0, M = 0, clips = 0, Cmax = 0, levels = 0, T = 0;
     uint32_t tangent_stride = 3;
@@ -51,11 +61,14 @@ struct CompiledRig {
     uint32_t max_tile_joints = 0;            // over LDS tiles
     uint32_t max_tile_joints_any = 0;
     uint32_t lds_tiles = 0;
-    // morph: per-vertex lists of (target, delta9), targets ascending
-    std::vector<uint32_t> mptr;         // [T*256+1]
-    std::vector<uint16_t> mtgt;         // [E]
-    std::vector<float> mdelta;          // [E][9]
+    // morph: (tile, target) pairs, targets ascending inside a tile
+    std::vector<uint32_t> tile_pair_start;  // [T+1]
+    std::vector<MorphPair> pairs;
+    std::vector<float> mblock;          // dense [9][256] blocks and sparse [cnt][9] deltas
+    std::vector<uint8_t> mmap;          // sparse pairs: [256] slot+1 (0 = vertex untouched)
     std::vector<float> default_weights; // [M]
+    uint32_t max_tile_pairs = 0;
+    uint64_t morph_entries = 0;         // nonzero (vertex, target) deltas kept
     // kept for skinrt_export_interleaved
     std::vector<uint16_t> joints0;      // [V][4]
     std::vector<float> weights0;        // [V][4]

@@ -172,18 +172,18 @@ def test_reference_layout_exports(oracle32):
     assert su.shape == (128, 28)
     assert_equal(su[:J], ref.palette[1], "SkinMatrix entries")
     assert (su[J:] == 0).all()
-    # TextureSkinVertex 60 B / ColorSkinVertex 68 B (buffer/vertex.rs:60-102)
+    # TextureSkinVertex 68 B / ColorSkinVertex 76 B (size_of the #[repr(C)] structs; SURVEY.md's 60/68 omit joint_index) (buffer/vertex.rs:60-102)
     V = rig.vertex_count
     uv = np.arange(V * 2, dtype=np.float32).reshape(V, 2)
-    tv = c.interleaved(1, abi.LAYOUT_TEXTURE_SKIN, uv).reshape(V, 60)
+    tv = c.interleaved(1, abi.LAYOUT_TEXTURE_SKIN, uv).reshape(V, 68)
     f = tv[:, :44].copy().view(np.float32).reshape(V, 11)
     assert_equal(f[:, 0:3], ref.position[1], "TextureSkinVertex.position")
     assert_equal(f[:, 3:5], uv, "TextureSkinVertex.tex_coords")
     assert_equal(f[:, 5:8], ref.normal[1], "TextureSkinVertex.normal")
     assert_equal(f[:, 8:11], ref.tangent[1], "TextureSkinVertex.tangent")
     assert_equal(tv[:, 44:52].copy().view(np.uint16).reshape(V, 4), rig.joints[0], "joint_index")
-    assert_equal(tv[:, 52:60].copy().view(np.float32).reshape(V, 4), rig.weights[0], "joint_weight")
-    cv = c.interleaved(2, abi.LAYOUT_COLOR_SKIN, None).reshape(V, 68)
+    assert_equal(tv[:, 52:68].copy().view(np.float32).reshape(V, 4), rig.weights[0], "joint_weight")
+    cv = c.interleaved(2, abi.LAYOUT_COLOR_SKIN, None).reshape(V, 76)
     g = cv[:, :52].copy().view(np.float32).reshape(V, 13)
     assert_equal(g[:, 0:3], ref.position[2], "ColorSkinVertex.position")
     assert (g[:, 3:7] == 0).all()
