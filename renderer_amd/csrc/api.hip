@@ -125,6 +125,17 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
     range = (range + p.batch - 1) / p.batch * p.batch;
     p.range = (uint32_t)range;
     p.ranges = I ? (I + p.range - 1) / p.range : 0;
+    // XCD split: as many tile chunks as keep the chunks balanced within 4 %, the rest of the 8
+    // XCDs split the ranges (small meshes: every XCD takes all tiles of its own ranges)
+    const uint32_t T = std::max<uint32_t>(1, r.T);
+    p.tile_chunks = 1;
+    for (uint32_t tcs = 8; tcs > 1; tcs >>= 1) {
+        const uint32_t per = (T + tcs - 1) / tcs;
+        if ((uint64_t)per * tcs * 100 <= (uint64_t)T * 104) { p.tile_chunks = tcs; break; }
+    }
+    p.tiles_per_chunk = (T + p.tile_chunks - 1) / p.tile_chunks;
+    const uint32_t rcs = 8 / p.tile_chunks;
+    p.ranges_per_chunk = (std::max<uint32_t>(1, p.ranges) + rcs - 1) / rcs;
     p.exact = cfg.exact_arithmetic ? 1 : 0;
     p.normalize = cfg.normalize_outputs ? 1 : 0;
     p.aabb = 0;

@@ -57,6 +57,11 @@ struct CrowdDev {
 struct SkinPlan {
     uint32_t range;     // instances per block (one block = one vertex tile x one instance range)
     uint32_t ranges;    // ceil(I / range)
+    // XCD-aware grid: 8 = tile_chunks x range chunks; XCD x owns tile chunk x % tile_chunks
+    // and range chunk x / tile_chunks
+    uint32_t tile_chunks;       // 1, 2, 4 or 8
+    uint32_t tiles_per_chunk;   // ceil(T / tile_chunks)
+    uint32_t ranges_per_chunk;  // ceil(ranges / (8 / tile_chunks))
     uint32_t batch;     // instances whose palettes are LDS-resident at once
     uint32_t jt_shift;  // log2 of the padded tile joint-list length
     uint32_t lds_tiles; // tiles whose joint list is LDS-staged (the rest gather from L2)

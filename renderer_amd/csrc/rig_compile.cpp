@@ -262,6 +262,12 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
                     const uint32_t jj = (w == 0.0f) ? list[0] : j;
                     li[a * TV + l] = (uint16_t)(lds ? local_of[jj] : jj);
                 }
+        // lanes past the last vertex repeat the tile's first vertex: they compute a position that
+        // already exists, so the bounds reduction needs no lane mask (their stores are masked)
+        for (uint32_t l = v1 - v0; l < TV; ++l) {
+            for (int e = 0; e < 9; ++e) b[e * TV + l] = b[e * TV];
+            for (uint32_t a = 0; a < W; ++a) { wt[a * TV + l] = wt[a * TV]; li[a * TV + l] = li[a * TV]; }
+        }
     }
     if (V) {
         r.joints0.assign(d->joints[0], d->joints[0] + (size_t)V * 4);
@@ -330,9 +336,12 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
                 float* blk = &r.mblock[mp.data_off];
                 for (size_t k = 0; k < pt.lv.size(); ++k)
                     for (int e = 0; e < 9; ++e) blk[e * TV + pt.lv[k]] = pt.dl[k * 9 + e];
+                for (uint32_t l = std::min(V - t * TV, TV); l < TV; ++l)  // padded lanes mirror lane 0
+                    for (int e = 0; e < 9; ++e) blk[e * TV + l] = blk[e * TV];
             } else {
                 r.mmap.resize(r.mmap.size() + TV, 0);
                 for (size_t k = 0; k < pt.lv.size(); ++k) r.mmap[mp.map_off + pt.lv[k]] = (uint8_t)(k + 1);
+                for (uint32_t l = std::min(V - t * TV, TV); l < TV; ++l) r.mmap[mp.map_off + l] = r.mmap[mp.map_off];
                 r.mblock.insert(r.mblock.end(), pt.dl.begin(), pt.dl.end());
             }
             REQUIRE(r.mblock.size() < (1ull << 32), SKINRT_E_INVALID, "morph delta pool exceeds 2^32 floats");
