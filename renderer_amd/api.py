@@ -21,7 +21,7 @@ import numpy as np
 from . import abi
 from .abi import Config, RigData, RigDesc, RigInfo
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libskinrt.so")
+_LIB_PATH = os.environ.get("SKINRT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libskinrt.so")
 _lib = None
 
 # every symbol include/skinrt.h declares

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -12,6 +13,9 @@
 #include "device_types.hpp"
 
 using namespace skinrt;
+#ifdef SKINRT_STAMPS
+namespace skinrt { void debug_dump_stamps(); }
+#endif
 
 namespace {
 
@@ -111,12 +115,16 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
     p.jt_shift = ceil_log2(std::max<uint32_t>(1, r.max_tile_joints));
     const uint32_t JTP = 1u << p.jt_shift;
     p.max_pairs = r.max_tile_pairs;
+    p.pair_gshift = std::min<uint32_t>(6, ceil_log2(std::max<uint32_t>(1, r.max_tile_pairs)));
     p.lds_tiles = r.lds_tiles;
     // per instance: palette rows, morph weights, bounds partials, active-pair list (+ count)
-    const uint32_t per_inst = JTP * 96 + r.M * 4 + 16 * 6 * 4 + (p.max_pairs + 1) * 4;
-    const uint32_t budget = 24 * 1024;
+    // (double-buffered: the loader wave fills one buffer while the compute waves read the other)
+    const uint32_t per_inst = 2 * (JTP * 96 + 16 * 6 * 4 + (p.max_pairs + 1) * 16);
+    // 4 blocks (20 waves) per CU share 160 KiB: keep a block under 40 KiB
+    const uint32_t fixed = (r.M ? 4 * kMorphSlots * kMorphWaveFloats * 4 : 0) + p.max_pairs * 16;
+    const uint32_t budget = fixed < 30 * 1024 ? 40 * 1024 - fixed : 10 * 1024;
     p.batch = std::min<uint32_t>(16, std::max<uint32_t>(1, budget / per_inst));
-    p.lds_bytes = p.batch * per_inst + p.max_pairs * 16;
+    p.lds_bytes = p.batch * per_inst + fixed;
     // enough blocks to fill 256 CUs several times over, but ranges long enough to amortise the
     // per-block vertex load
     const uint64_t want_blocks = 4096;
@@ -139,6 +147,11 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
     p.exact = cfg.exact_arithmetic ? 1 : 0;
     p.normalize = cfg.normalize_outputs ? 1 : 0;
     p.aabb = 0;
+    p.debug = 0;
+#ifdef SKINRT_STAMPS
+    fprintf(stderr, "[skinrt plan] I=%u T=%u jt_shift=%u max_pairs=%u batch=%u range=%u ranges=%u lds=%u tile_chunks=%u\n", I, r.T,
+            p.jt_shift, p.max_pairs, p.batch, p.range, p.ranges, p.lds_bytes, p.tile_chunks);
+#endif
     return p;
 }
 
@@ -233,7 +246,7 @@ int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig**
 #define UP(field) if ((rc = upload(r, h.field, &d.field)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
     UP(parent) UP(rest_trs) UP(rest_mat) UP(node_matrix) UP(level_start) UP(level_nodes) UP(node_chan)
     UP(chans) UP(clip_chan_count) UP(times) UP(values) UP(joint_node) UP(ibm) UP(base) UP(wts) UP(lidx)
-    UP(tile_joint_start) UP(tile_joints) UP(tile_lds) UP(tile_pair_start) UP(pairs) UP(mblock) UP(mmap)
+    UP(tile_joint_start) UP(tile_joints) UP(tile_lds) UP(tile_pair_start) UP(pairs) UP(mblock)
 #undef UP
     if ((rc = upload(r, h.default_weights, &defw)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
     r->default_mw = r->bufs.back();
@@ -249,6 +262,9 @@ int skinrt_get_rig_info(skinrt_rig* rig, skinrt_rig_info* out_info) {
 
 int skinrt_destroy_crowd(skinrt_crowd* c) {
     if (!c) return SKINRT_OK;
+#ifdef SKINRT_STAMPS
+    if (c->ctx) { (void)hipSetDevice(c->ctx->cfg.device); (void)hipStreamSynchronize(c->ctx->stream); skinrt::debug_dump_stamps(); }
+#endif
     if (c->ctx) {
         (void)hipSetDevice(c->ctx->cfg.device);
         (void)hipStreamSynchronize(c->ctx->stream);

@@ -33,7 +33,6 @@ struct RigDev {
     const uint32_t* tile_pair_start;
     const MorphPair* pairs;
     const float* mblock;
-    const uint8_t* mmap;
 };
 
 // Per-crowd state and outputs (HBM layout: DESIGN.md §3).
@@ -65,11 +64,13 @@ struct SkinPlan {
     uint32_t batch;     // instances whose palettes are LDS-resident at once
     uint32_t jt_shift;  // log2 of the padded tile joint-list length
     uint32_t lds_tiles; // tiles whose joint list is LDS-staged (the rest gather from L2)
+    uint32_t pair_gshift; // log2 of the lane-group size the loader uses to compact one instance's pairs
     uint32_t max_pairs; // largest number of (tile, target) morph pairs in one tile
     uint32_t lds_bytes; // dynamic LDS per block
     uint32_t exact;     // 1: contraction-free arithmetic (bit-equal to the fp32 oracle)
     uint32_t normalize; // shader.wgsl:217-218 variant
     uint32_t aabb;      // write per-(instance,tile) bounds
+    uint32_t debug;     // SKINRT_DEBUG ablation bits (timing experiments only)
 };
 
 enum PosePath : uint32_t { kPoseWave = 0, kPoseSplit = 1 };

@@ -22,6 +22,14 @@ namespace skinrt {
 
 namespace {
 
+#ifdef SKINRT_STAMPS
+// Diagnostic build only (make stamps): per-segment cycle sums over all waves; never in the product.
+__device__ unsigned long long g_stamps[16];
+#define STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_[k] += now_ - last_; last_ = now_; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -80,6 +88,14 @@ __device__ __forceinline__ void row_minmax6(float& a0, float& a1, float& a2, flo
 #undef SKINRT_DPP_STEP
 }
 
+// Barrier that orders LDS only.  __syncthreads() also fences global memory, i.e. waits for every
+// outstanding store of the wave (s_waitcnt vmcnt(0)) — here that would drain the 36 B/vertex
+// output stream at every batch and serialise the store path with the math.  Written as asm so the
+// compiler cannot widen it to vmcnt(0) on account of the LDS-DMA loads it sees in this kernel.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct LdsPal {
     const f4* base;  // this instance's staged palette: [list position][6]
     __device__ __forceinline__ const f4* entry(uint32_t idx) const { return base + idx * 6; }
@@ -91,24 +107,28 @@ struct GlobalPal {
 
 // Position pass then normal/tangent pass: the two accumulators are never live together and each
 // influence's rows are consumed as they arrive, which keeps the kernel at 4 waves per SIMD.
+// Scalar v_fma_f32 on purpose (the file is built with -fno-slp-vectorize): on gfx950 a
+// v_pk_fma_f32 costs more issue time than the two v_fma_f32 it replaces.
 template <bool EXACT, int K, class Pal>
 __device__ __forceinline__ void skin_position(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
                                               const float (&p)[3], float (&op)[3]) {
-    f2 S[6];  // rows of the blended 3x4: S[2r] = (m_r0, m_r1), S[2r+1] = (m_r2, m_r3)
+    float S[12];  // rows of the blended 3x4
 #pragma unroll
     for (int a = 0; a < 4 * K; ++a) {
         const f4* e = pal.entry(li[a]);
         const f4 r0 = e[0], r1 = e[1], r2 = e[2];
-        const f2 m[6] = {r0.xy, r0.zw, r1.xy, r1.zw, r2.xy, r2.zw};
+        const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
 #pragma unroll
-        for (int x = 0; x < 6; ++x) S[x] = a == 0 ? mul2(w[0], m[x]) : madd2<EXACT>(w[a], m[x], S[x]);
+        for (int x = 0; x < 12; ++x) S[x] = a == 0 ? mul_nc(w[0], m[x]) : madd<EXACT>(w[a], m[x], S[x]);
+        // two influences' rows in flight at a time: bounds the live registers (5 waves per SIMD)
+        if ((a & 1) && a + 1 < 4 * K) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        float s = mul_nc(S[2 * r].x, p[0]);
-        s = madd<EXACT>(S[2 * r].y, p[1], s);
-        s = madd<EXACT>(S[2 * r + 1].x, p[2], s);
-        op[r] = add_nc(s, S[2 * r + 1].y);
+        float s = mul_nc(S[4 * r], p[0]);
+        s = madd<EXACT>(S[4 * r + 1], p[1], s);
+        s = madd<EXACT>(S[4 * r + 2], p[2], s);
+        op[r] = add_nc(s, S[4 * r + 3]);
     }
 }
 
@@ -116,23 +136,25 @@ template <bool EXACT, int K, class Pal>
 __device__ __forceinline__ void skin_normal(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
                                             const float (&n)[3], const float (&t)[3], bool normalize,
                                             float (&on)[3], float (&ot)[3]) {
-    f2 Nm[6];  // rows of the blended normal matrix, 4th component of each row is padding (0)
+    float Nm[9];  // rows of the blended normal matrix
 #pragma unroll
     for (int a = 0; a < 4 * K; ++a) {
         const f4* e = pal.entry(li[a]);
-        const f4 n0 = e[3], n1 = e[4], n2 = e[5];
-        const f2 q[6] = {n0.xy, n0.zw, n1.xy, n1.zw, n2.xy, n2.zw};
+        const f4 n0 = e[3], n1 = e[4], n2 = e[5];  // full 16-byte rows: ds_read_b128, not the slower b96
+        const float q[9] = {n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, n2.x, n2.y, n2.z};
+        asm volatile("" ::"v"(n0.w), "v"(n1.w), "v"(n2.w));
 #pragma unroll
-        for (int x = 0; x < 6; ++x) Nm[x] = a == 0 ? mul2(w[0], q[x]) : madd2<EXACT>(w[a], q[x], Nm[x]);
+        for (int x = 0; x < 9; ++x) Nm[x] = a == 0 ? mul_nc(w[0], q[x]) : madd<EXACT>(w[a], q[x], Nm[x]);
+        if ((a & 1) && a + 1 < 4 * K) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        float a = mul_nc(Nm[2 * r].x, n[0]);
-        a = madd<EXACT>(Nm[2 * r].y, n[1], a);
-        on[r] = madd<EXACT>(Nm[2 * r + 1].x, n[2], a);
-        float b = mul_nc(Nm[2 * r].x, t[0]);
-        b = madd<EXACT>(Nm[2 * r].y, t[1], b);
-        ot[r] = madd<EXACT>(Nm[2 * r + 1].x, t[2], b);
+        float a = mul_nc(Nm[3 * r], n[0]);
+        a = madd<EXACT>(Nm[3 * r + 1], n[1], a);
+        on[r] = madd<EXACT>(Nm[3 * r + 2], n[2], a);
+        float b = mul_nc(Nm[3 * r], t[0]);
+        b = madd<EXACT>(Nm[3 * r + 1], t[1], b);
+        ot[r] = madd<EXACT>(Nm[3 * r + 2], t[2], b);
     }
     if (normalize) {  // shader.wgsl:217-218 — v / sqrt(dot(v,v))
         const float ln = sqrtf(madd<true>(on[2], on[2], madd<true>(on[1], on[1], mul_nc(on[0], on[0]))));
@@ -152,6 +174,81 @@ __device__ __forceinline__ void morph_add(float mw, const float (&d)[9], float (
     }
 }
 
+// One (tile, target) pair applied to this lane's vertex.
+//   dense : `src` = this WAVE's share [9][64] (LDS slot, or mblock + wave * 576)
+//   sparse: `src` = the whole region [256 B slot map][cnt][9]
+template <bool EXACT>
+__device__ __forceinline__ void morph_pair(const float* src, bool dense, uint32_t tid, float mw,
+                                           float (&p)[3], float (&n)[3], float (&t)[3]) {
+    if (dense) {
+        float d[9];
+#pragma unroll
+        for (int x = 0; x < 9; ++x) d[x] = src[x * 64 + (tid & 63)];
+        morph_add<EXACT>(mw, d, p, n, t);
+    } else {
+        const uint32_t slot = reinterpret_cast<const uint8_t*>(src)[tid];
+        if (slot) {
+            const float* dp = src + kTileVerts / 4 + (slot - 1) * 9;
+            float d[9];
+#pragma unroll
+            for (int x = 0; x < 9; ++x) d[x] = dp[x];
+            morph_add<EXACT>(mw, d, p, n, t);
+        }
+    }
+}
+
+// 16 bytes per lane, global (uniform base + lane byte offset + IMM) -> LDS (lds_base + IMM + lane*16),
+// with no register destination.  Written as asm: the compiler's wait-count pass treats an LDS-DMA
+// it can see as aliasing every later LDS read and answers with s_waitcnt vmcnt(0), which here would
+// also wait for the wave's output stores.  All waits for these loads are placed by hand.  m0 is
+// written here and nowhere else in this file (gfx9 LDS instructions do not read it), and it cannot
+// be named as a clobber.
+#define SKINRT_GLDS(IMM)                                                                                  \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #IMM             \
+                 : : "v"(lane_bytes), "s"(gbase), "s"(lds_base) : "memory")
+
+// Start the LDS-DMA of up to kMorphSlots active pairs of one instance into this wave's slots.
+// act: the instance's records {mblock float offset, weight bits, dense, region floats}.
+__device__ __forceinline__ void morph_dma_issue(const float* mblock, const uint4* act, uint32_t na, float* slots,
+                                                uint32_t wave, uint32_t lane) {
+    const uint32_t ns = min(na, kMorphSlots);
+    const uint32_t lane_bytes = lane * 16;
+    for (uint32_t a = 0; a < ns; ++a) {
+        const uint4 rc = act[1 + a];
+        const uint32_t doff = __builtin_amdgcn_readfirstlane(rc.x);
+        const bool dense = __builtin_amdgcn_readfirstlane(rc.z) != 0;
+        const uint32_t n4 = dense ? kMorphWaveFloats / 4 : (__builtin_amdgcn_readfirstlane(rc.w) + 3) / 4;
+        const float* gbase = mblock + (doff + (dense ? wave * kMorphWaveFloats : 0u));  // wave-uniform
+        const uint32_t lds_base = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(slots + a * kMorphWaveFloats));
+        if (lane < n4) SKINRT_GLDS(0);
+        if (lane + 64 < n4) SKINRT_GLDS(1024);
+        if (lane + 128 < n4) SKINRT_GLDS(2048);
+    }
+}
+
+typedef float float3v __attribute__((ext_vector_type(3)));
+
+// 12-byte store to (wave-uniform base) + (per-lane byte offset).  The s_nop covers the wait state a
+// >8-byte store needs before its data registers may be overwritten (the compiler's hazard pass does
+// not look inside asm).
+__device__ __forceinline__ void store3(float* base, uint32_t byte_off, const float (&x)[3]) {
+    float3v d = {x[0], x[1], x[2]};
+#ifndef SKINRT_STORE_POLICY
+#define SKINRT_STORE_POLICY 1  // nt: the outputs are a pure stream, keep L2 for palettes / morph deltas (measured: -7 %)
+#endif
+#if SKINRT_STORE_POLICY == 1
+#define SKINRT_STORE_MOD " nt"
+#elif SKINRT_STORE_POLICY == 2
+#define SKINRT_STORE_MOD " sc1"
+#elif SKINRT_STORE_POLICY == 3
+#define SKINRT_STORE_MOD " sc0 sc1 nt"
+#else
+#define SKINRT_STORE_MOD ""
+#endif
+    asm volatile("global_store_dwordx3 %0, %1, %2" SKINRT_STORE_MOD "\n\ts_nop 1" : : "v"(byte_off), "v"(d), "s"(base) : "memory");
+}
+
 struct Outputs {
     float* pos;
     float* nrm;
@@ -162,23 +259,36 @@ struct Outputs {
 template <bool EXACT, int K, class Pal>
 __device__ __forceinline__ void skin_store(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
                                            const float (&p)[3], const float (&n)[3], const float (&t)[3],
-                                           bool normalize, bool valid, const Outputs& out, size_t o, float (&op)[3]) {
+                                           bool normalize, bool valid, const Outputs& out, size_t obase, uint32_t olb, float (&op)[3]) {
+    // obase (instance offset) is wave-uniform and olb (vertex byte offset) fits 32 bits: the three
+    // stores take the SGPR-base + VGPR-offset form and share one offset register.  Left to itself
+    // the compiler hoists three 64-bit per-lane pointers out of the instance loop and spills them.
     float on[3], ot[3];
     skin_position<EXACT, K>(pal, w, li, p, op);
-    if (valid) *reinterpret_cast<float3*>(out.pos + o) = make_float3(op[0], op[1], op[2]);
+    if (valid) store3(out.pos + obase, olb, op);
     skin_normal<EXACT, K>(pal, w, li, n, t, normalize, on, ot);
     if (valid) {
-        *reinterpret_cast<float3*>(out.nrm + o) = make_float3(on[0], on[1], on[2]);
-        *reinterpret_cast<float3*>(out.tan + o) = make_float3(ot[0], ot[1], ot[2]);
+        store3(out.nrm + obase, olb, on);
+        store3(out.tan + obase, olb, ot);
     }
 }
 
+constexpr uint32_t kSkinThreads = 320;  // 4 compute waves (256 vertices) + 1 loader wave
+
+// Producer / consumer block.  Waves 0-3 own the tile's 256 vertices: inside the instance loop they
+// only read LDS, do math and issue stores — never a vector-memory LOAD, whose wait (vmcnt counts
+// loads and stores together, in order) would drain the wave's whole output stream.  Wave 4 is the
+// loader: while the others work on batch k it stages batch k+1 (palette rows of the tile's joints,
+// active morph-pair records) into the other LDS buffer and writes batch k-1's bounds.  One
+// LDS-only barrier per batch hands the buffers over.
 template <bool EXACT, int K, bool LDSPAL>
-__global__ __launch_bounds__(256, (K == 1 ? 4 : 2)) void k_skin(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
+__global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave == 4;
     // block -> (tile, range): blocks b and b+8 share an XCD (round-robin dispatch); each XCD owns
     // a contiguous chunk of tiles x a chunk of ranges, so a tile's mesh/morph data and a range's
     // palette rows stay in ONE L2.  Placement is a speed matter only.
@@ -196,13 +306,130 @@ __global__ __launch_bounds__(256, (K == 1 ? 4 : 2)) void k_skin(const RigDev rig
     const uint32_t B = plan.batch;
     const uint32_t M = rig.M;
     const uint32_t P1 = plan.max_pairs + 1;
-    f4* pal_s = reinterpret_cast<f4*>(smem);                              // [B][JTP][6]
-    MorphPair* pairs_s = reinterpret_cast<MorphPair*>(pal_s + (size_t)B * JTP * 6);  // [max_pairs]
-    float* mw_s = reinterpret_cast<float*>(pairs_s + plan.max_pairs);     // [B][M]
-    float* ab_s = mw_s + (size_t)B * M;                                   // [B][16][6]
-    uint32_t* act_s = reinterpret_cast<uint32_t*>(ab_s + (size_t)B * 16 * 6);  // [B][1 + max_pairs]
+    // LDS: two buffers of per-batch data, then the block-lifetime morph tables
+    f4* pal_s = reinterpret_cast<f4*>(smem);                              // [2][B][JTP][6]
+    float* ab_s = reinterpret_cast<float*>(pal_s + (size_t)2 * B * JTP * 6);  // [2][B][16][6]
+    // per instance: [0].x = number of active pairs, then one record per active pair:
+    // {mblock float offset, weight bits, dense flag, region floats}
+    uint4* act_s = reinterpret_cast<uint4*>(ab_s + (size_t)2 * B * 16 * 6);   // [2][B][1 + max_pairs]
+    MorphPair* pairs_s = reinterpret_cast<MorphPair*>(act_s + (size_t)2 * B * P1);  // [max_pairs]
+    float* ml_s = reinterpret_cast<float*>(pairs_s + plan.max_pairs);     // [4 waves][kMorphSlots][576]
+    const uint32_t pal_buf = B * JTP * 6, ab_buf = B * 16 * 6, act_buf = B * P1;
 
-    // ---- this thread's vertex ------------------------------------------------------------
+    const uint32_t pbeg = rig.tile_pair_start[tile];
+    const uint32_t np = rig.tile_pair_start[tile + 1] - pbeg;
+    const uint32_t jstart = rig.tile_joint_start[tile];
+    const uint32_t jcnt = rig.tile_joint_start[tile + 1] - jstart;
+    const f4* pal_g = reinterpret_cast<const f4*>(cr.palette);
+    const uint32_t nbatch = (i1 - i0 + B - 1) / B;
+
+    // ---- block prologue: morph tables into LDS (all waves), this thread's vertex (waves 0-3) --
+    for (uint32_t c = tid; c < np; c += kSkinThreads) pairs_s[c] = rig.pairs[pbeg + c];
+    lds_barrier();  // pairs_s visible to every wave
+
+    if (loader) {
+        // ================= loader wave =================
+        // Its registers never coexist with the compute waves' (the roles never rejoin), which keeps
+        // the whole kernel at 96 VGPRs = 5 waves per SIMD.
+        // lane state that does not change from batch to batch: its palette piece (joint, quarter)
+        // and, when the tile has at most 64 pairs, its (instance-in-group, pair) slot
+        const uint32_t c0 = lane;
+        const uint32_t lj0 = c0 / 6, q0 = c0 - lj0 * 6;
+        const uint32_t j0 = (LDSPAL && c0 < jcnt * 6) ? rig.tile_joints[jstart + lj0] : 0u;
+        const uint32_t G = 1u << plan.pair_gshift;
+        const uint32_t gq = lane & (G - 1), gb = lane >> plan.pair_gshift;
+        const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+        MorphPair mymp{};
+        if (gq < np && np <= 64) mymp = pairs_s[gq];
+
+        // stage batch `kb` into LDS buffer `buf`
+        auto stage = [&](uint32_t kb, uint32_t buf) {
+            const uint32_t ib = i0 + kb * B;
+            const uint32_t nb = min(B, i1 - ib);
+            uint4* actb = act_s + buf * act_buf;
+            // (1) morph weight of this lane's (instance, pair) slot: issue the load first
+            float mw_first = 0.0f;
+            if (np <= 64 && gb < nb && gq < np) mw_first = cr.mw[(size_t)(ib + gb) * M + mymp.target];
+            // (2) palette rows of the tile's joints: a lane owns one 16-byte piece (joint, quarter)
+            // and walks the batch's instances, four loads in flight at a time
+            if (LDSPAL) {
+                const size_t istride = (size_t)rig.J * 6;
+                const uint32_t dstride = JTP * 6;
+                for (uint32_t c = lane; c < jcnt * 6; c += 64) {
+                    uint32_t j = j0, q = q0;
+                    if (c != c0) { const uint32_t lj = c / 6; q = c - lj * 6; j = rig.tile_joints[jstart + lj]; }
+                    const f4* src = pal_g + (size_t)ib * istride + (size_t)j * 6 + q;
+                    f4* dst = pal_s + buf * pal_buf + c;
+                    uint32_t b = 0;
+                    for (; b + 4 <= nb; b += 4) {
+                        const f4 x0 = src[(size_t)b * istride], x1 = src[(size_t)(b + 1) * istride];
+                        const f4 x2 = src[(size_t)(b + 2) * istride], x3 = src[(size_t)(b + 3) * istride];
+                        dst[b * dstride] = x0; dst[(b + 1) * dstride] = x1;
+                        dst[(b + 2) * dstride] = x2; dst[(b + 3) * dstride] = x3;
+                    }
+                    for (; b < nb; ++b) dst[b * dstride] = src[(size_t)b * istride];
+                }
+            }
+            // (3) the tile's pairs whose weight is non-zero for the instance (zero weights add
+            // exactly 0), compacted in target order with a wave ballot.  Up to 64 pairs: groups of
+            // G lanes take one instance each, so one round of loads covers 64/G instances.
+            if (np <= 64) {
+                for (uint32_t b0 = 0; b0 < nb; b0 += 64 >> plan.pair_gshift) {
+                    const uint32_t b = b0 + gb;
+                    const bool live = b < nb && gq < np;
+                    const float mw = b0 == 0 ? mw_first : (live ? cr.mw[(size_t)(ib + b) * M + mymp.target] : 0.0f);
+                    const bool on = mw != 0.0f;
+                    const unsigned long long seg = (__ballot(on) >> (gb << plan.pair_gshift)) & gmask;
+                    if (on) actb[b * P1 + 1 + __popcll(seg & ((1ull << gq) - 1ull))] =
+                                make_uint4(mymp.data_off, __float_as_uint(mw), mymp.dense, mymp.floats);
+                    if (gq == 0 && b < nb) actb[b * P1] = make_uint4((uint32_t)__popcll(seg), 0, 0, 0);
+                }
+            } else {
+                for (uint32_t b = 0; b < nb; ++b) {
+                    uint4* act = actb + b * P1;
+                    const float* mwg = cr.mw + (size_t)(ib + b) * M;
+                    uint32_t n = 0;
+                    for (uint32_t qq = 0; qq < np; qq += 64) {
+                        const uint32_t q = qq + lane;
+                        MorphPair mp{};
+                        float mw = 0.0f;
+                        if (q < np) { mp = pairs_s[q]; mw = mwg[mp.target]; }
+                        const bool on = mw != 0.0f;
+                        const unsigned long long mask = __ballot(on);
+                        if (on) act[1 + n + __popcll(mask & ((1ull << lane) - 1ull))] =
+                                    make_uint4(mp.data_off, __float_as_uint(mw), mp.dense, mp.floats);
+                        n += __popcll(mask);
+                    }
+                    if (lane == 0) act[0] = make_uint4(n, 0, 0, 0);
+                }
+            }
+        };
+        // bounds of batch `kb` (16 DPP-row partials per instance, written by the compute waves)
+        auto flush_bounds = [&](uint32_t kb, uint32_t buf) {
+            const uint32_t ib = i0 + kb * B;
+            const uint32_t nb = min(B, i1 - ib);
+            for (uint32_t idx = lane; idx < nb * 6; idx += 64) {
+                const uint32_t b = idx / 6, c = idx - b * 6;
+                const float* src = ab_s + buf * ab_buf + (size_t)b * 16 * 6 + c;
+                float r = src[0];
+                for (int q = 1; q < 16; ++q) r = c < 3 ? fminf(r, src[q * 6]) : fmaxf(r, src[q * 6]);
+                cr.aabb_part[((size_t)(ib + b) * rig.T + tile) * 6 + c] = r;
+            }
+        };
+
+        stage(0, 0);
+        lds_barrier();
+        for (uint32_t kb = 0; kb < nbatch; ++kb) {
+            const uint32_t buf = kb & 1;
+            if (kb + 1 < nbatch) stage(kb + 1, buf ^ 1);
+            if (plan.aabb && kb > 0) flush_bounds(kb - 1, buf ^ 1);
+            lds_barrier();
+        }
+        if (plan.aabb) flush_bounds(nbatch - 1, (nbatch - 1) & 1);
+        return;
+    }
+
+    // ================= compute waves: this thread's vertex =================
     const uint32_t v = tile * TV + tid;
     const bool valid = v < rig.V;
     float p0[3], n0[3], t0[3], w[W];
@@ -216,104 +443,93 @@ __global__ __launch_bounds__(256, (K == 1 ? 4 : 2)) void k_skin(const RigDev rig
 #pragma unroll
         for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
     }
-    // morph: this tile's (tile, target) pairs; their records live in LDS for the whole block
-    const uint32_t pbeg = rig.tile_pair_start[tile];
-    const uint32_t np = rig.tile_pair_start[tile + 1] - pbeg;
-    for (uint32_t c = tid; c < np; c += 256) pairs_s[c] = rig.pairs[pbeg + c];
-    const uint32_t jstart = rig.tile_joint_start[tile];
-    const uint32_t jcnt = rig.tile_joint_start[tile + 1] - jstart;
-    const f4* pal_g = reinterpret_cast<const f4*>(cr.palette);
-    const uint32_t lane = tid & 63, wave = tid >> 6;
     const Outputs out{cr.pos, cr.nrm, cr.tan};
+    const uint32_t olb = v * 12;  // byte offset of this lane's vertex inside an instance's output
     const bool normalize = plan.normalize != 0;
+    float* my_slots = ml_s + (size_t)wave * kMorphSlots * kMorphWaveFloats;
+    // vector-memory ops this wave issues per instance after the morph DMA: 3 stores, or none when no
+    // lane of the wave holds a real vertex (tail of the last tile)
+    const uint32_t stores_per_instance = __builtin_amdgcn_readfirstlane(__ballot(valid) != 0ull ? 3u : 0u);
+    lds_barrier();  // batch 0 is staged
 
-    for (uint32_t ib = i0; ib < i1; ib += B) {
+#ifdef SKINRT_STAMPS
+    unsigned long long acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long last_ = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t kb = 0; kb < nbatch; ++kb) {
+        const uint32_t buf = kb & 1;
+        const uint32_t ib = i0 + kb * B;
         const uint32_t nb = min(B, i1 - ib);
-        __syncthreads();  // previous batch's readers are done with LDS (and pairs_s is visible)
-        if (LDSPAL) {
-            const uint32_t chunks = (nb << plan.jt_shift) * 6;
-            for (uint32_t c = tid; c < chunks; c += 256) {
-                const uint32_t row = c / 6, q = c - row * 6;
-                const uint32_t b = row >> plan.jt_shift, lj = row & (JTP - 1);
-                if (lj < jcnt) {
-                    const uint32_t j = rig.tile_joints[jstart + lj];
-                    pal_s[c] = pal_g[((size_t)(ib + b) * rig.J + j) * 6 + q];
-                }
-            }
-        }
-        for (uint32_t c = tid; c < nb * M; c += 256) mw_s[c] = cr.mw[(size_t)ib * M + c];
-        // per instance: which of the tile's pairs have a non-zero weight (zero weights add exactly 0)
-        if (tid < nb) {
-            uint32_t* act = act_s + tid * P1;
-            const float* mwg = cr.mw + (size_t)(ib + tid) * M;
-            uint32_t n = 0;
-            for (uint32_t q = 0; q < np; ++q)
-                if (mwg[pairs_s[q].target] != 0.0f) act[++n] = q;
-            act[0] = n;
-        }
-        __syncthreads();
-
+        uint32_t na_next = act_s[buf * act_buf].x;
+        bool dma_pending = false;  // this instance's pairs were requested during the previous one
         for (uint32_t b = 0; b < nb; ++b) {
             const uint32_t i = ib + b;
-            const size_t o = ((size_t)i * rig.V + v) * 3;
-            const uint32_t* act = act_s + b * P1;
-            const uint32_t na = __builtin_amdgcn_readfirstlane(act[0]);
+            const size_t obase = (size_t)i * rig.V * 3;
+            const uint4* act = act_s + buf * act_buf + b * P1;
+            const uint32_t na = __builtin_amdgcn_readfirstlane(na_next);
+            if (b + 1 < nb) na_next = act[P1].x;  // next instance's count arrives during this one
+            STAMP(0);
             float op[3];
             auto skin = [&](const float (&p)[3], const float (&n)[3], const float (&t)[3]) {
-                if constexpr (LDSPAL) skin_store<EXACT, K>(LdsPal{pal_s + (size_t)b * JTP * 6}, w, li, p, n, t, normalize, valid, out, o, op);
-                else skin_store<EXACT, K>(GlobalPal{pal_g + (size_t)i * rig.J * 6}, w, li, p, n, t, normalize, valid, out, o, op);
+                if constexpr (LDSPAL) skin_store<EXACT, K>(LdsPal{pal_s + buf * pal_buf + (size_t)b * JTP * 6}, w, li, p, n, t, normalize, valid, out, obase, olb, op);
+                else skin_store<EXACT, K>(GlobalPal{pal_g + (size_t)i * rig.J * 6}, w, li, p, n, t, normalize, valid, out, obase, olb, op);
             };
-            if (na == 0) {
-                skin(p0, n0, t0);  // no active morph target touches this tile for this instance
-            } else {
-                // a13: p = p0 + sum_m w_m * delta_m, targets ascending (wave-uniform loop)
-                float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
-                for (uint32_t a = 1; a <= na; ++a) {
-                    const uint32_t q = __builtin_amdgcn_readfirstlane(act[a]);
-                    const MorphPair mp = pairs_s[q];
-                    const uint32_t doff = __builtin_amdgcn_readfirstlane(mp.data_off);
-                    const float mw = mw_s[b * M + __builtin_amdgcn_readfirstlane((uint32_t)mp.target)];
-                    if (__builtin_amdgcn_readfirstlane(mp.dense)) {
-                        const float* blk = rig.mblock + doff + tid;
-                        float d[9];
-#pragma unroll
-                        for (int x = 0; x < 9; ++x) d[x] = blk[x * TV];
-                        morph_add<EXACT>(mw, d, p, n, t);
-                    } else {
-                        const uint32_t slot = rig.mmap[__builtin_amdgcn_readfirstlane(mp.map_off) + tid];
-                        if (slot) {
-                            const float* dp = rig.mblock + doff + (slot - 1) * 9;
-                            float d[9];
-#pragma unroll
-                            for (int x = 0; x < 9; ++x) d[x] = dp[x];
-                            morph_add<EXACT>(mw, d, p, n, t);
-                        }
-                    }
+            // Morph data reaches this wave through LDS-DMA requested one instance ahead, so the wait
+            // below is "all but my 3 newest vector-memory ops" = the previous instance's stores may
+            // still be in flight.  A plain load here would have to wait for them (vmcnt is in order).
+            float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
+            if (na) {
+                if (!dma_pending) {  // first instance of a batch: request now, wait for everything
+                    morph_dma_issue(rig.mblock, act, na, my_slots, wave, lane);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (stores_per_instance == 3) {
+                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                skin(p, n, t);
+                STAMP(1);
+                // a13: p = p0 + sum_m w_m * delta_m, targets ascending (wave-uniform loop)
+                for (uint32_t a = 1; a <= na; ++a) {
+                    const uint4 cur = act[a];
+                    const float mw = __uint_as_float(cur.y);
+                    const bool dense = __builtin_amdgcn_readfirstlane(cur.z) != 0;
+                    if (a <= kMorphSlots) morph_pair<EXACT>(my_slots + (a - 1) * kMorphWaveFloats, dense, tid, mw, p, n, t);
+                    else  // more active pairs than slots: plain loads (rare; these do drain the stores)
+                        morph_pair<EXACT>(rig.mblock + __builtin_amdgcn_readfirstlane(cur.x) + (dense ? wave * kMorphWaveFloats : 0u),
+                                          dense, tid, mw, p, n, t);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slot reads retired before the slots are refilled
             }
+            STAMP(2);
+            // request the next instance's pairs before this instance's stores are issued
+            dma_pending = false;
+            if (b + 1 < nb) {
+                const uint32_t nn = __builtin_amdgcn_readfirstlane(na_next);
+                if (nn) { morph_dma_issue(rig.mblock, act + P1, nn, my_slots, wave, lane); dma_pending = true; }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the 3 stores below younger than the DMA above
+            skin(p, n, t);
+            STAMP(3);
             if (plan.aabb) {
                 // lanes past the mesh end repeat a real vertex (rig_compile), so no mask is needed
                 float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
                 row_minmax6(a0, a1, a2, b0, b1, b2);
                 if ((lane & 15) == 0) {
-                    float* dst = ab_s + ((size_t)b * 16 + wave * 4 + (lane >> 4)) * 6;
+                    float* dst = ab_s + buf * ab_buf + ((size_t)b * 16 + wave * 4 + (lane >> 4)) * 6;
                     dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = b0; dst[4] = b1; dst[5] = b2;
                 }
             }
+            STAMP(4);
         }
-        if (plan.aabb) {
-            __syncthreads();
-            if (tid < nb * 6) {
-                const uint32_t b = tid / 6, c = tid - b * 6;
-                const float* src = ab_s + (size_t)b * 16 * 6 + c;
-                float r = src[0];
-                for (int q = 1; q < 16; ++q) r = c < 3 ? fminf(r, src[q * 6]) : fmaxf(r, src[q * 6]);
-                cr.aabb_part[((size_t)(ib + b) * rig.T + tile) * 6 + c] = r;
-            }
-        }
+        lds_barrier();
+        STAMP(5);
     }
+#ifdef SKINRT_STAMPS
+    if (lane == 0)
+        for (int q = 0; q < 16; ++q) atomicAdd(&g_stamps[q], acc_[q]);
+#endif
 }
+
 
 // a14: bounds of one instance = min/max over its tiles' partial bounds (order-independent, exact)
 __global__ __launch_bounds__(256) void k_aabb_reduce(const RigDev rig, const CrowdDev cr) {
@@ -333,7 +549,7 @@ __global__ __launch_bounds__(256) void k_fill_mw(float* mw, const float* default
 
 template <bool EXACT, bool LDSPAL>
 hipError_t launch_skin_k(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s) {
-    const dim3 grid(8u * plan.tiles_per_chunk * plan.ranges_per_chunk), block(256);
+    const dim3 grid(8u * plan.tiles_per_chunk * plan.ranges_per_chunk), block(kSkinThreads);
     switch (rig.K) {
         case 1: hipLaunchKernelGGL((k_skin<EXACT, 1, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
         case 2: hipLaunchKernelGGL((k_skin<EXACT, 2, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
@@ -355,6 +571,23 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         e = plan.exact ? launch_skin_k<true, false>(rig, cr, plan, s) : launch_skin_k<false, false>(rig, cr, plan, s);
     return e;
 }
+
+#ifdef SKINRT_STAMPS
+void debug_dump_stamps() {
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) != hipSuccess) return;
+    static const char* names[16] = {"C inst-top(act read)", "C morph DMA wait", "C morph", "C skin (to last store)", "C aabb",
+                                    "C barrier wait", "", "", "L stage", "L flush bounds", "L barrier wait",
+                                    "", "", "", "", ""};
+    double tot = 0;
+    for (int q = 0; q < 12; ++q) tot += (double)h[q];
+    for (int q = 0; q < 12; ++q)
+        if (h[q]) printf("stamp %-22s %6.2f %%  %8.1f Mcycles\n", names[q], 100.0 * (double)h[q] / tot, (double)h[q] * 1e-6);
+    fflush(stdout);
+    for (int q = 0; q < 16; ++q) h[q] = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), h, sizeof h);
+}
+#endif
 
 hipError_t launch_aabb_reduce(const RigDev& rig, const CrowdDev& cr, hipStream_t s) {
     if (cr.I == 0) return hipSuccess;

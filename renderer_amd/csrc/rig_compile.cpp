@@ -324,31 +324,35 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
     for (uint32_t t = 0; t < T; ++t) {
         r.tile_pair_start[t + 1] = r.tile_pair_start[t] + (uint32_t)per_tile[t].size();
         r.max_tile_pairs = std::max<uint32_t>(r.max_tile_pairs, (uint32_t)per_tile[t].size());
+        const uint32_t nvalid = std::min(V - t * TV, TV);
         for (const PairTmp& pt : per_tile[t]) {
             MorphPair mp{};
             mp.target = (uint16_t)pt.target;
-            mp.cnt = (uint16_t)pt.lv.size();
-            mp.dense = pt.lv.size() >= kMorphDenseMin ? 1u : 0u;
+            mp.dense = pt.lv.size() >= kMorphDenseMin ? 1 : 0;
             mp.data_off = (uint32_t)r.mblock.size();
-            mp.map_off = (uint32_t)r.mmap.size();
             if (mp.dense) {
-                r.mblock.resize(r.mblock.size() + 9 * TV, 0.0f);
+                mp.floats = 9 * TV;
+                r.mblock.resize(r.mblock.size() + mp.floats, 0.0f);
                 float* blk = &r.mblock[mp.data_off];
+                auto at = [&](uint32_t lane, int e) -> float& { return blk[(lane / 64) * kMorphWaveFloats + e * 64 + (lane % 64)]; };
                 for (size_t k = 0; k < pt.lv.size(); ++k)
-                    for (int e = 0; e < 9; ++e) blk[e * TV + pt.lv[k]] = pt.dl[k * 9 + e];
-                for (uint32_t l = std::min(V - t * TV, TV); l < TV; ++l)  // padded lanes mirror lane 0
-                    for (int e = 0; e < 9; ++e) blk[e * TV + l] = blk[e * TV];
+                    for (int e = 0; e < 9; ++e) at(pt.lv[k], e) = pt.dl[k * 9 + e];
+                for (uint32_t l = nvalid; l < TV; ++l)  // padded lanes mirror lane 0
+                    for (int e = 0; e < 9; ++e) at(l, e) = at(0, e);
             } else {
-                r.mmap.resize(r.mmap.size() + TV, 0);
-                for (size_t k = 0; k < pt.lv.size(); ++k) r.mmap[mp.map_off + pt.lv[k]] = (uint8_t)(k + 1);
-                for (uint32_t l = std::min(V - t * TV, TV); l < TV; ++l) r.mmap[mp.map_off + l] = r.mmap[mp.map_off];
-                r.mblock.insert(r.mblock.end(), pt.dl.begin(), pt.dl.end());
+                mp.floats = (TV / 4 + (uint32_t)pt.dl.size() + 3) & ~3u;
+                r.mblock.resize(r.mblock.size() + mp.floats, 0.0f);
+                uint8_t* map = reinterpret_cast<uint8_t*>(&r.mblock[mp.data_off]);
+                for (size_t k = 0; k < pt.lv.size(); ++k) map[pt.lv[k]] = (uint8_t)(k + 1);
+                for (uint32_t l = nvalid; l < TV; ++l) map[l] = map[0];
+                std::memcpy(&r.mblock[mp.data_off + TV / 4], pt.dl.data(), pt.dl.size() * 4);
             }
             REQUIRE(r.mblock.size() < (1ull << 32), SKINRT_E_INVALID, "morph delta pool exceeds 2^32 floats");
             r.pairs.push_back(mp);
         }
         std::vector<PairTmp>().swap(per_tile[t]);
     }
+    r.mblock.resize(r.mblock.size() + 256, 0.0f);  // slack so a full-wave 16-byte piece never reads past the pool
 }
 
 int compile_rig(const skinrt_rig_desc* desc, const skinrt_config* cfg, CompiledRig& out, std::string& err) {

@@ -25,13 +25,23 @@ struct ChanRec {
 
 // one morph target's effect on one vertex tile
 struct MorphPair {
-    uint32_t data_off;  // into mblock[]: dense -> [9][256] SoA; sparse -> [cnt][9]
-    uint32_t map_off;   // into mmap[] (sparse only)
+    // float offset of the pair's region in mblock[] (multiple of 4 floats):
+    //   dense : [4 waves][9 attrs][64 lanes] — each wave's 576 floats are contiguous so the wave
+    //           can pull its share into LDS with three 16-byte LDS-DMA loads
+    //   sparse: [256 B slot map: slot+1 per tile lane, 0 = untouched][cnt][9], cnt < kMorphDenseMin
+    uint32_t data_off;
+    uint32_t floats;    // size of the region in floats (sparse: <= kMorphWaveFloats)
     uint16_t target;
-    uint16_t cnt;       // touched vertices
-    uint32_t dense;
+    uint16_t dense;
+    uint32_t reserved;
 };
-constexpr uint32_t kMorphDenseMin = 96;  // touched vertices from which a pair is stored dense
+constexpr uint32_t kMorphWaveFloats = 576;    // one wave's share of a dense pair = one LDS slot
+constexpr uint32_t kMorphDenseMin = 57;       // touched vertices from which a pair is stored dense
+                                              // (a sparse region, 64 + 56*9 floats, still fits a slot)
+#ifndef SKINRT_MORPH_SLOTS
+#define SKINRT_MORPH_SLOTS 2
+#endif
+constexpr uint32_t kMorphSlots = SKINRT_MORPH_SLOTS;  // LDS slots per wave: active pairs streamed per instance
 
 struct CompiledRig {
     uint32_t N = 0, J = 0, V = 0, K = 0, M = 0, clips = 0, Cmax = 0, levels = 0, T = 0;
@@ -64,8 +74,7 @@ struct CompiledRig {
     // morph: (tile, target) pairs, targets ascending inside a tile
     std::vector<uint32_t> tile_pair_start;  // [T+1]
     std::vector<MorphPair> pairs;
-    std::vector<float> mblock;          // dense [9][256] blocks and sparse [cnt][9] deltas
-    std::vector<uint8_t> mmap;          // sparse pairs: [256] slot+1 (0 = vertex untouched)
+    std::vector<float> mblock;          // pair regions (see MorphPair::data_off)
     std::vector<float> default_weights; // [M]
     uint32_t max_tile_pairs = 0;
     uint64_t morph_entries = 0;         // nonzero (vertex, target) deltas kept
