@@ -1,0 +1,229 @@
+"""C-ABI boundary and host logic, CPU only: the shared library loads, exports every symbol the
+header declares, the header is plain C and its struct layouts agree with the ctypes mirror, and
+the host-side validation (`skinrt_validate_rig`, no device calls) reports the documented error
+codes.  No compute entry point is called here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from renderer_amd import abi, api, synth
+from renderer_amd.abi import Channel, MorphTarget
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "skinrt.h")
+
+
+def header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(skinrt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = api.load_library()
+    declared = header_functions()
+    assert len(declared) >= 27
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/skinrt.h but not exported"
+    assert sorted(api.EXPORTS) == declared
+
+
+def test_no_unexpected_exports():
+    out = subprocess.run(["nm", "-D", "--defined-only", api.lib_path()], capture_output=True, text=True, check=True).stdout
+    names = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    extra = [n for n in names if not n.startswith("skinrt_")]
+    assert not extra, f"library exports non-API symbols: {extra[:5]}"
+
+
+def test_abi_version_matches_header():
+    m = re.search(r"#define\s+SKINRT_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    assert api.load_library().skinrt_abi_version() == int(m.group(1))
+
+
+def test_header_is_plain_c_and_layouts_match_ctypes(tmp_path):
+    src = tmp_path / "layout.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "skinrt.h"
+#define S(T) printf(#T " %zu\n", sizeof(T))
+#define O(T, f) printf(#T "." #f " %zu\n", offsetof(T, f))
+int main(void) {
+    S(skinrt_config); O(skinrt_config, device); O(skinrt_config, exact_arithmetic); O(skinrt_config, pose_path);
+    S(skinrt_channel_desc); O(skinrt_channel_desc, times); O(skinrt_channel_desc, values);
+    S(skinrt_clip_desc); O(skinrt_clip_desc, channels);
+    S(skinrt_morph_target_desc); O(skinrt_morph_target_desc, tangent);
+    S(skinrt_rig_desc); O(skinrt_rig_desc, joint_node); O(skinrt_rig_desc, clips); O(skinrt_rig_desc, position);
+    O(skinrt_rig_desc, tangent_stride); O(skinrt_rig_desc, joints); O(skinrt_rig_desc, targets); O(skinrt_rig_desc, default_weights);
+    S(skinrt_rig_info); O(skinrt_rig_info, morph_entries); O(skinrt_rig_info, device_bytes);
+    return 0;
+}
+''')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    got = dict(l.rsplit(" ", 1) for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    mirror = {"skinrt_config": abi.Config, "skinrt_channel_desc": abi.ChannelDesc, "skinrt_clip_desc": abi.ClipDesc,
+              "skinrt_morph_target_desc": abi.MorphTargetDesc, "skinrt_rig_desc": abi.RigDesc, "skinrt_rig_info": abi.RigInfo}
+    for key, val in got.items():
+        if "." in key:
+            t, f = key.split(".")
+            assert getattr(mirror[t], f).offset == int(val), key
+        else:
+            assert C.sizeof(mirror[key]) == int(val), key
+
+
+def test_error_codes_match_header():
+    text = open(HEADER).read()
+    for name in ("OK", "E_INVALID", "E_DEVICE", "E_NOMEM", "E_NONAFFINE", "E_RANGE", "E_LIMIT"):
+        m = re.search(rf"#define\s+SKINRT_{name}\s+\(?(-?\d+)\)?", text)
+        assert m, name
+        assert getattr(abi, name) == int(m.group(1)), name
+
+
+# ---- host-side validation (skinrt_validate_rig: pure host, runs without a GPU) ----------------------------------
+
+def tiny():
+    spec = synth.tiny_spec(seed=3)
+    return spec, synth.make_rig(spec)
+
+
+def expect(rig, code, needle, **cfg):
+    with pytest.raises(api.SkinrtError) as e:
+        api.validate_rig(rig, api.make_config(**cfg) if cfg else None)
+    assert e.value.code == code, e.value
+    assert needle in e.value.message, e.value.message
+
+
+def test_validate_reports_rig_info():
+    spec, rig = tiny()
+    info = api.validate_rig(rig)
+    assert (info.node_count, info.joint_count, info.vertex_count) == (spec.nodes, spec.joints, spec.verts)
+    assert info.set_count == 1 and info.target_count == spec.targets and info.clip_count == spec.clips
+    assert info.tile_vertices == 256 and info.tile_count == 1
+    assert info.max_channels == rig.max_channels
+    assert 1 <= info.level_count <= spec.nodes
+
+
+def test_validate_tile_and_level_counts():
+    spec = synth.scaled(synth.CONFIGS["c1"])
+    info = api.validate_rig(synth.make_rig(spec))
+    assert info.tile_count == (3273 + 255) // 256
+    assert info.level_count <= spec.max_depth + 1
+
+
+def test_parent_order_rejected():
+    _, rig = tiny()
+    rig.parent = rig.parent.copy(); rig.parent[2] = 5   # child before its parent: not a pre-order walk
+    expect(rig, abi.E_INVALID, "DFS pre-order")
+
+
+def test_joint_index_out_of_range():
+    _, rig = tiny()
+    rig.joints[0] = rig.joints[0].copy(); rig.joints[0][3, 1] = rig.joint_count
+    rig.weights[0] = rig.weights[0].copy(); rig.weights[0][3, 1] = 0.5
+    expect(rig, abi.E_RANGE, "joint index out of range")
+
+
+def test_joint_node_out_of_range():
+    _, rig = tiny()
+    rig.joint_node = rig.joint_node.copy(); rig.joint_node[0] = rig.node_count
+    expect(rig, abi.E_RANGE, "joint_node out of range")
+
+
+def test_non_affine_inverse_bind():
+    _, rig = tiny()
+    rig.inverse_bind = rig.inverse_bind.copy(); rig.inverse_bind[1, 3] = 0.25   # column 0, row 3
+    expect(rig, abi.E_NONAFFINE, "inverse bind matrix last row")
+
+
+def test_unsorted_key_times():
+    _, rig = tiny()
+    ch = rig.clips[0][0]
+    ch.times = ch.times[::-1].copy()
+    expect(rig, abi.E_INVALID, "not sorted")
+
+
+def test_duplicate_channel_target():
+    _, rig = tiny()
+    a = rig.clips[0][0]
+    rig.clips[0].append(Channel(a.target_node, a.path, a.interpolation, a.times.copy(), a.values.copy()))
+    expect(rig, abi.E_INVALID, "same node property")
+
+
+def test_morph_weight_channel_path_rejected():
+    _, rig = tiny()
+    rig.clips[0][0].path = 3   # MorphTargetWeights: todo!() in the reference loader
+    expect(rig, abi.E_INVALID, "channel path invalid")
+
+
+def test_channel_target_out_of_range():
+    _, rig = tiny()
+    rig.clips[0][0].target_node = 1000
+    expect(rig, abi.E_RANGE, "target_node out of range")
+
+
+def test_non_finite_inputs_rejected():
+    _, rig = tiny()
+    rig.translation = rig.translation.copy(); rig.translation[0, 0] = np.nan
+    expect(rig, abi.E_INVALID, "non-finite node transform")
+    _, rig = tiny()
+    rig.weights[0] = rig.weights[0].copy(); rig.weights[0][0, 0] = np.inf
+    expect(rig, abi.E_INVALID, "non-finite joint weight")
+
+
+def test_dense_target_length_mismatch():
+    _, rig = tiny()
+    desc = rig.to_desc()
+    desc.targets[0].count = rig.vertex_count - 1   # dense target (indices NULL) must cover every vertex
+    lib = api.load_library()
+    assert lib.skinrt_validate_rig(None, C.byref(desc), None) == abi.E_INVALID
+    assert b"dense morph target count" in lib.skinrt_last_error()
+
+
+def test_sparse_target_indices_checked():
+    _, rig = tiny()
+    rig.targets[0] = MorphTarget(position=np.zeros((2, 3), np.float32), indices=np.array([5, 5], np.uint32))
+    expect(rig, abi.E_INVALID, "strictly increasing")
+    rig.targets[0] = MorphTarget(position=np.zeros((1, 3), np.float32), indices=np.array([rig.vertex_count], np.uint32))
+    expect(rig, abi.E_RANGE, "vertex index out of range")
+
+
+def test_reference_limits_mode():
+    # uniform/skin.rs:10 MAX_JOINTS = 128 and the shader's single weight set are opt-in limits
+    spec = synth.tiny_spec(seed=4, nodes=140, joints=130, max_depth=10)
+    rig = synth.make_rig(spec)
+    api.validate_rig(rig)
+    expect(rig, abi.E_LIMIT, "128 joints", reference_limits=1)
+    spec = synth.tiny_spec(seed=4, sets=2)
+    expect(synth.make_rig(spec), abi.E_LIMIT, "set 0 only", reference_limits=1)
+
+
+def test_struct_size_guard():
+    _, rig = tiny()
+    desc = rig.to_desc()
+    desc.struct_size = 8
+    rc = api.load_library().skinrt_validate_rig(None, C.byref(desc), None)
+    assert rc == abi.E_INVALID
+
+
+def test_null_handles_are_errors_not_crashes():
+    lib = api.load_library()
+    assert lib.skinrt_evaluate(None, abi.STAGE_ALL) == abi.E_INVALID
+    assert lib.skinrt_set_clocks(None, None, None) == abi.E_INVALID
+    assert lib.skinrt_get_rig_info(None, None) == abi.E_INVALID
+    assert lib.skinrt_destroy_crowd(None) in (abi.OK, abi.E_INVALID)
+    assert b"NULL" in lib.skinrt_last_error() or lib.skinrt_last_error() != b""
+
+
+def test_init_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.SkinrtError) as e:
+        api.Context()
+    assert e.value.code == abi.E_DEVICE
