@@ -6,10 +6,12 @@ hierarchy propagation -> joint palette -> morph + linear-blend skinning -> per-i
 (skinrt_evaluate(STAGE_ALL)), plus, for N > 1, the RCCL all-gather of the bounds.  Inputs
 (rig tables, clocks, morph weights) are resident in HBM before the timed region.
 
-Workload: N=1 -> BASELINE.json configs[2] (C3: VRM-shaped avatar, 60k verts, 200 joints,
-4 weights, 32 morph targets x 10,000 instances — the config the roofline target is quoted on);
-N>1 -> configs[3] (C4: the same avatar x 100,000 instances sharded over the N GPUs).
-`--workload c2|c5` benches the other single-GPU configs.  Synthetic rigs (renderer_amd/synth.py).
+Workload: BASELINE.json configs[2] (C3: VRM-shaped avatar, 60k verts, 200 joints, 4 weights,
+32 morph targets x 10,000 instances — the config the roofline target is quoted on) PER GPU:
+N=1 is C3 itself; N>1 shards 10,000*N instances over the N ranks (weak scaling, no data-path
+collective, one all-gather of the bounds per frame).  `--workload c4` runs configs[3] (the same
+avatar x 100,000 instances over the N GPUs, strong scaling); `--workload c2|c5` bench the other
+single-GPU configs.  Synthetic rigs (renderer_amd/synth.py).
 
 Prints ONE JSON line on rank 0.
 """
@@ -100,9 +102,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = max(args.gpus, world)
 
-    name = args.workload or ("c3" if n_gpus == 1 else "c4")
+    # Default: weak scaling — every GPU evaluates a C3-sized shard (10,000 instances), so the job
+    # is C3 at N=1 and 80,000 avatars at N=8 (BASELINE's C4 is 100,000 over the node: 12,500 per
+    # GPU at N=8; `--workload c4` runs exactly that, total fixed = strong scaling).
+    name = args.workload or "c3"
     spec = synth.CONFIGS[name]
-    total = args.instances or spec.instances
+    weak = name != "c4"
+    total = args.instances or (spec.instances * world if weak else spec.instances)
     lo, hi = shard.shard_range(total, rank, world)
     mine = hi - lo
     rig_data = synth.make_rig(spec)
@@ -171,7 +177,7 @@ def main():
         out = {
             "metric": "skinned vertices/sec (whole node) + ms/frame at N avatars; % HBM roofline",
             "value": value, "unit": "skinned vertices/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if n_gpus == 1 else "strong",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{name}: VRM-shaped avatar x instances" if name in ("c3", "c4") else name,
                        "instances_total": total, "instances_per_gpu": mine, "vertices": V,

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Round profile of the bench command on the GPU box: rocprofv3 kernel trace + stats, then PMC
+# passes (each its own run), summarised into gpurun_out/<tag>/summary.txt and traffic.json.
+# usage: tools/round_profile.sh <tag> [bench args...]     e.g. tools/round_profile.sh r01_c3 --steps 5 --warmup 2
+set -u
+TAG=$1; shift
+tools/prof.sh $TAG "$@" || exit 1
+python3 tools/prof_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.txt || exit 1
+python3 tools/make_traffic.py gpurun_out/$TAG "$@" > gpurun_out/$TAG/traffic.json || exit 1
+cat gpurun_out/$TAG/summary.txt | grep -E "k_skin|k_pose|k_aabb|==" | head -40
+cat gpurun_out/$TAG/traffic.json
