@@ -121,7 +121,8 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
     // (double-buffered: the loader wave fills one buffer while the compute waves read the other)
     const uint32_t per_inst = 2 * (JTP * 96 + 16 * 6 * 4 + (p.max_pairs + 1) * 16);
     // 4 blocks (20 waves) per CU share 160 KiB: keep a block under 40 KiB
-    const uint32_t fixed = (r.M ? 4 * kMorphSlots * kMorphWaveFloats * 4 : 0) + p.max_pairs * 16;
+    // block-lifetime tables: per-wave morph slots, the tile's pair records, instance order (mask + perm)
+    const uint32_t fixed = (r.M ? 4 * kMorphSlots * kMorphWaveFloats * 4 : 0) + p.max_pairs * 16 + 256 * 4 + 256 * 2;
     const uint32_t budget = fixed < 30 * 1024 ? 40 * 1024 - fixed : 10 * 1024;
     p.batch = std::min<uint32_t>(16, std::max<uint32_t>(1, budget / per_inst));
     p.lds_bytes = p.batch * per_inst + fixed;
@@ -131,6 +132,8 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
     uint64_t range = ((uint64_t)I * std::max<uint32_t>(1, r.T) + want_blocks - 1) / want_blocks;
     range = std::min<uint64_t>(std::max<uint64_t>(range, p.batch), 256);
     range = (range + p.batch - 1) / p.batch * p.batch;
+    // the kernel's per-block instance-order tables hold 256 entries: never more than that per block
+    if (range > 256) range = 256 / p.batch * p.batch;
     p.range = (uint32_t)range;
     p.ranges = I ? (I + p.range - 1) / p.range : 0;
     // XCD split: as many tile chunks as keep the chunks balanced within 4 %, the rest of the 8

@@ -30,6 +30,13 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP(k) do { } while (0)
 #endif
 
+// Diagnostic builds only (-DSKINRT_ABLATE=bits): 1 = skip the morph arithmetic, 2 = skip the morph
+// LDS-DMA, 4 = loader reports no active pairs, 8 = dense deltas from registers (no LDS read),
+// 16 = dense deltas read but not applied.  Results are wrong by design; timing experiments.
+#ifndef SKINRT_ABLATE
+#define SKINRT_ABLATE 0
+#endif
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -183,8 +190,13 @@ __device__ __forceinline__ void morph_pair(const float* src, bool dense, uint32_
     if (dense) {
         float d[9];
 #pragma unroll
-        for (int x = 0; x < 9; ++x) d[x] = src[x * 64 + (tid & 63)];
-        morph_add<EXACT>(mw, d, p, n, t);
+        for (int x = 0; x < 9; ++x) d[x] = (SKINRT_ABLATE & 8) ? p[x % 3] : src[x * 64 + (tid & 63)];
+        if (SKINRT_ABLATE & 16) {
+#pragma unroll
+            for (int x = 0; x < 9; ++x) asm volatile("" ::"v"(d[x]));
+        } else {
+            morph_add<EXACT>(mw, d, p, n, t);
+        }
     } else {
         const uint32_t slot = reinterpret_cast<const uint8_t*>(src)[tid];
         if (slot) {
@@ -211,7 +223,7 @@ __device__ __forceinline__ void morph_pair(const float* src, bool dense, uint32_
 // act: the instance's records {mblock float offset, weight bits, dense, region floats}.
 __device__ __forceinline__ void morph_dma_issue(const float* mblock, const uint4* act, uint32_t na, float* slots,
                                                 uint32_t wave, uint32_t lane) {
-    const uint32_t ns = min(na, kMorphSlots);
+    const uint32_t ns = (SKINRT_ABLATE & 2) ? 0u : min(na, kMorphSlots);
     const uint32_t lane_bytes = lane * 16;
     for (uint32_t a = 0; a < ns; ++a) {
         const uint4 rc = act[1 + a];
@@ -314,6 +326,10 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const R
     uint4* act_s = reinterpret_cast<uint4*>(ab_s + (size_t)2 * B * 16 * 6);   // [2][B][1 + max_pairs]
     MorphPair* pairs_s = reinterpret_cast<MorphPair*>(act_s + (size_t)2 * B * P1);  // [max_pairs]
     float* ml_s = reinterpret_cast<float*>(pairs_s + plan.max_pairs);     // [4 waves][kMorphSlots][576]
+    // processing order of the block's instances (see the loader prologue): active-pair mask per
+    // instance-in-range, and the order itself
+    uint32_t* mask_s = reinterpret_cast<uint32_t*>(ml_s + (rig.M ? 4 * kMorphSlots * kMorphWaveFloats : 0u));  // [256]
+    uint16_t* perm_s = reinterpret_cast<uint16_t*>(mask_s + 256);                    // [256]
     const uint32_t pal_buf = B * JTP * 6, ab_buf = B * 16 * 6, act_buf = B * P1;
 
     const uint32_t pbeg = rig.tile_pair_start[tile];
@@ -342,14 +358,70 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const R
         MorphPair mymp{};
         if (gq < np && np <= 64) mymp = pairs_s[gq];
 
+        // ---- processing order: instances with the same SET of active pairs become neighbours ----
+        // Outputs go to each instance's own rows, so the order inside a block is free.  Sorted by
+        // active-pair mask, a run of instances finds its pairs already in the waves' LDS slots and
+        // only the first of the run streams them in (C3: ~9 distinct sets per 256 instances).
+        // mask bit q = pair q active (pairs >= 31 share bit 31, which is never trusted as "same").
+        const uint32_t nin = i1 - i0;  // <= 256 (plan.range)
+        if (np == 0) {
+            for (uint32_t kk = lane; kk < 256; kk += 64) { mask_s[kk] = 0; perm_s[kk] = (uint16_t)kk; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            uint32_t mym[4], rank[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t kk = lane + 64 * r;
+                uint32_t m = 0xffffffffu;  // padding sorts last
+                if (kk < nin) {
+                    m = 0;
+                    const float* mwg = cr.mw + (size_t)(i0 + kk) * M;
+                    for (uint32_t q = 0; q < np; ++q)
+                        if (mwg[pairs_s[q].target] != 0.0f) m |= 1u << min(q, 31u);
+                }
+                mym[r] = m;
+                mask_s[kk] = m;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: its own LDS writes are now readable
+            // rank = number of (mask, index) keys below mine; keys are distinct, so ranks are a permutation
+            for (uint32_t j = 0; j < 256; j += 4) {
+                const uint4 mj = *reinterpret_cast<const uint4*>(mask_s + j);
+                const uint32_t mjs[4] = {mj.x, mj.y, mj.z, mj.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t kk = lane + 64 * r;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        rank[r] += (mjs[u] < mym[r] || (mjs[u] == mym[r] && j + u < kk)) ? 1u : 0u;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t kk = lane + 64 * r;
+                perm_s[rank[r]] = (uint16_t)kk;  // padded keys take the ranks >= nin
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const bool exact_mask = np <= 32;
+        auto inst_at = [&](uint32_t pos) -> uint32_t { return i0 + perm_s[pos]; };
+        // header of the instance at `pos`: {active pairs | reload << 16, instance, 0, 0}; reload = its
+        // active set differs from its predecessor's in the block's order (slots must be refilled)
+        auto header = [&](uint32_t pos, uint32_t count) -> uint4 {
+            const uint32_t m = mask_s[perm_s[pos]];
+            const uint32_t prev = pos ? mask_s[perm_s[pos - 1]] : ~m;
+            const uint32_t reload = (m != prev || (!exact_mask && (m >> 31))) ? 1u : 0u;
+            if (SKINRT_ABLATE & 4) count = 0;
+            return make_uint4(count | (reload << 16), inst_at(pos), 0, 0);
+        };
+
         // stage batch `kb` into LDS buffer `buf`
         auto stage = [&](uint32_t kb, uint32_t buf) {
-            const uint32_t ib = i0 + kb * B;
-            const uint32_t nb = min(B, i1 - ib);
+            const uint32_t pos0 = kb * B;
+            const uint32_t nb = min(B, nin - pos0);
             uint4* actb = act_s + buf * act_buf;
             // (1) morph weight of this lane's (instance, pair) slot: issue the load first
             float mw_first = 0.0f;
-            if (np <= 64 && gb < nb && gq < np) mw_first = cr.mw[(size_t)(ib + gb) * M + mymp.target];
+            if (np <= 64 && gb < nb && gq < np) mw_first = cr.mw[(size_t)inst_at(pos0 + gb) * M + mymp.target];
             // (2) palette rows of the tile's joints: a lane owns one 16-byte piece (joint, quarter)
             // and walks the batch's instances, four loads in flight at a time
             if (LDSPAL) {
@@ -358,16 +430,17 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const R
                 for (uint32_t c = lane; c < jcnt * 6; c += 64) {
                     uint32_t j = j0, q = q0;
                     if (c != c0) { const uint32_t lj = c / 6; q = c - lj * 6; j = rig.tile_joints[jstart + lj]; }
-                    const f4* src = pal_g + (size_t)ib * istride + (size_t)j * 6 + q;
+                    const f4* src = pal_g + (size_t)j * 6 + q;
                     f4* dst = pal_s + buf * pal_buf + c;
                     uint32_t b = 0;
                     for (; b + 4 <= nb; b += 4) {
-                        const f4 x0 = src[(size_t)b * istride], x1 = src[(size_t)(b + 1) * istride];
-                        const f4 x2 = src[(size_t)(b + 2) * istride], x3 = src[(size_t)(b + 3) * istride];
+                        const uint32_t ia = inst_at(pos0 + b), ib1 = inst_at(pos0 + b + 1), ic = inst_at(pos0 + b + 2), id = inst_at(pos0 + b + 3);
+                        const f4 x0 = src[(size_t)ia * istride], x1 = src[(size_t)ib1 * istride];
+                        const f4 x2 = src[(size_t)ic * istride], x3 = src[(size_t)id * istride];
                         dst[b * dstride] = x0; dst[(b + 1) * dstride] = x1;
                         dst[(b + 2) * dstride] = x2; dst[(b + 3) * dstride] = x3;
                     }
-                    for (; b < nb; ++b) dst[b * dstride] = src[(size_t)b * istride];
+                    for (; b < nb; ++b) dst[b * dstride] = src[(size_t)inst_at(pos0 + b) * istride];
                 }
             }
             // (3) the tile's pairs whose weight is non-zero for the instance (zero weights add
@@ -377,17 +450,17 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const R
                 for (uint32_t b0 = 0; b0 < nb; b0 += 64 >> plan.pair_gshift) {
                     const uint32_t b = b0 + gb;
                     const bool live = b < nb && gq < np;
-                    const float mw = b0 == 0 ? mw_first : (live ? cr.mw[(size_t)(ib + b) * M + mymp.target] : 0.0f);
+                    const float mw = b0 == 0 ? mw_first : (live ? cr.mw[(size_t)inst_at(pos0 + b) * M + mymp.target] : 0.0f);
                     const bool on = mw != 0.0f;
                     const unsigned long long seg = (__ballot(on) >> (gb << plan.pair_gshift)) & gmask;
                     if (on) actb[b * P1 + 1 + __popcll(seg & ((1ull << gq) - 1ull))] =
                                 make_uint4(mymp.data_off, __float_as_uint(mw), mymp.dense, mymp.floats);
-                    if (gq == 0 && b < nb) actb[b * P1] = make_uint4((uint32_t)__popcll(seg), 0, 0, 0);
+                    if (gq == 0 && b < nb) actb[b * P1] = header(pos0 + b, (uint32_t)__popcll(seg));
                 }
             } else {
                 for (uint32_t b = 0; b < nb; ++b) {
                     uint4* act = actb + b * P1;
-                    const float* mwg = cr.mw + (size_t)(ib + b) * M;
+                    const float* mwg = cr.mw + (size_t)inst_at(pos0 + b) * M;
                     uint32_t n = 0;
                     for (uint32_t qq = 0; qq < np; qq += 64) {
                         const uint32_t q = qq + lane;
@@ -400,20 +473,20 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const R
                                     make_uint4(mp.data_off, __float_as_uint(mw), mp.dense, mp.floats);
                         n += __popcll(mask);
                     }
-                    if (lane == 0) act[0] = make_uint4(n, 0, 0, 0);
+                    if (lane == 0) act[0] = header(pos0 + b, n);
                 }
             }
         };
         // bounds of batch `kb` (16 DPP-row partials per instance, written by the compute waves)
         auto flush_bounds = [&](uint32_t kb, uint32_t buf) {
-            const uint32_t ib = i0 + kb * B;
-            const uint32_t nb = min(B, i1 - ib);
+            const uint32_t pos0 = kb * B;
+            const uint32_t nb = min(B, nin - pos0);
             for (uint32_t idx = lane; idx < nb * 6; idx += 64) {
                 const uint32_t b = idx / 6, c = idx - b * 6;
                 const float* src = ab_s + buf * ab_buf + (size_t)b * 16 * 6 + c;
                 float r = src[0];
                 for (int q = 1; q < 16; ++q) r = c < 3 ? fminf(r, src[q * 6]) : fmaxf(r, src[q * 6]);
-                cr.aabb_part[((size_t)(ib + b) * rig.T + tile) * 6 + c] = r;
+                cr.aabb_part[((size_t)inst_at(pos0 + b) * rig.T + tile) * 6 + c] = r;
             }
         };
 
@@ -458,16 +531,25 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const R
 #endif
     for (uint32_t kb = 0; kb < nbatch; ++kb) {
         const uint32_t buf = kb & 1;
-        const uint32_t ib = i0 + kb * B;
-        const uint32_t nb = min(B, i1 - ib);
-        uint32_t na_next = act_s[buf * act_buf].x;
+        const uint32_t nb = min(B, (i1 - i0) - kb * B);
+        // header {active pairs | reload << 16, instance}: the loader orders the block's instances so
+        // that equal active sets are neighbours; reload = the slots hold another set.  Kept in
+        // SGPRs; the next one is fetched at the top of an instance and made scalar after its morph.
+        uint32_t hx, hi;
+        {
+            const uint2 h0 = *reinterpret_cast<const uint2*>(act_s + buf * act_buf);
+            hx = __builtin_amdgcn_readfirstlane(h0.x);
+            hi = __builtin_amdgcn_readfirstlane(h0.y);
+        }
         bool dma_pending = false;  // this instance's pairs were requested during the previous one
         for (uint32_t b = 0; b < nb; ++b) {
-            const uint32_t i = ib + b;
-            const size_t obase = (size_t)i * rig.V * 3;
             const uint4* act = act_s + buf * act_buf + b * P1;
-            const uint32_t na = __builtin_amdgcn_readfirstlane(na_next);
-            if (b + 1 < nb) na_next = act[P1].x;  // next instance's count arrives during this one
+            const uint32_t i = hi;
+            const uint32_t na = hx & 0xffffu;
+            const bool reload = (hx >> 16) != 0;
+            const size_t obase = (size_t)i * rig.V * 3;
+            uint2 hdr_next = make_uint2(0, 0);
+            if (b + 1 < nb) hdr_next = *reinterpret_cast<const uint2*>(act + P1);  // arrives during the morph
             STAMP(0);
             float op[3];
             auto skin = [&](const float (&p)[3], const float (&n)[3], const float (&t)[3]) {
@@ -479,17 +561,35 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const R
             // still be in flight.  A plain load here would have to wait for them (vmcnt is in order).
             float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
             if (na) {
-                if (!dma_pending) {  // first instance of a batch: request now, wait for everything
-                    morph_dma_issue(rig.mblock, act, na, my_slots, wave, lane);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else if (stores_per_instance == 3) {
-                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // records of the two slot pairs, requested before the DMA wait so that their LDS
+                // latency overlaps it (act[2] is readable LDS even when na == 1; unused then)
+                const uint2 r1 = *reinterpret_cast<const uint2*>(&act[1].y);  // {weight bits, dense}
+                const uint2 r2 = *reinterpret_cast<const uint2*>(&act[2].y);
+                if (reload) {
+                    if (!dma_pending) {  // first instance of a batch: request now, wait for everything
+                        morph_dma_issue(rig.mblock, act, na, my_slots, wave, lane);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else if (stores_per_instance == 3) {
+                        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
                 }
                 STAMP(1);
                 // a13: p = p0 + sum_m w_m * delta_m, targets ascending (wave-uniform loop)
-                for (uint32_t a = 1; a <= na; ++a) {
+                // wave-uniform: weights and flags move to SGPRs
+                const float mw1 = __uint_as_float(__builtin_amdgcn_readfirstlane(r1.x));
+                const float mw2 = __uint_as_float(__builtin_amdgcn_readfirstlane(r2.x));
+                const bool dense1 = __builtin_amdgcn_readfirstlane(r1.y) != 0;
+                const bool dense2 = __builtin_amdgcn_readfirstlane(r2.y) != 0;
+                uint32_t a = 1;
+                if (kMorphSlots >= 2 && !(SKINRT_ABLATE & 1)) {
+                    // the two slot pairs: their records are already scalar, so each costs one LDS round trip
+                    morph_pair<EXACT>(my_slots, dense1, tid, mw1, p, n, t);
+                    if (na >= 2) morph_pair<EXACT>(my_slots + kMorphWaveFloats, dense2, tid, mw2, p, n, t);
+                    a = 3;
+                }
+                for (; a <= ((SKINRT_ABLATE & 1) ? 0u : na); ++a) {
                     const uint4 cur = act[a];
                     const float mw = __uint_as_float(cur.y);
                     const bool dense = __builtin_amdgcn_readfirstlane(cur.z) != 0;
@@ -503,10 +603,9 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const R
             STAMP(2);
             // request the next instance's pairs before this instance's stores are issued
             dma_pending = false;
-            if (b + 1 < nb) {
-                const uint32_t nn = __builtin_amdgcn_readfirstlane(na_next);
-                if (nn) { morph_dma_issue(rig.mblock, act + P1, nn, my_slots, wave, lane); dma_pending = true; }
-            }
+            hx = __builtin_amdgcn_readfirstlane(hdr_next.x);
+            hi = __builtin_amdgcn_readfirstlane(hdr_next.y);
+            if ((hx & 0xffffu) && (hx >> 16)) { morph_dma_issue(rig.mblock, act + P1, hx & 0xffffu, my_slots, wave, lane); dma_pending = true; }
             __builtin_amdgcn_sched_barrier(0);  // keep the 3 stores below younger than the DMA above
             skin(p, n, t);
             STAMP(3);
@@ -515,7 +614,12 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const R
                 float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
                 row_minmax6(a0, a1, a2, b0, b1, b2);
                 if ((lane & 15) == 0) {
-                    float* dst = ab_s + buf * ab_buf + ((size_t)b * 16 + wave * 4 + (lane >> 4)) * 6;
+                    // lane id recomputed here (2 VALU ops) instead of kept live across the loop: at 96
+                    // VGPRs the loop-invariant row index was the value the allocator spilled, and its
+                    // scratch reload (a vector-memory load) drained the stores of every instance
+                    uint32_t lid;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+                    float* dst = ab_s + buf * ab_buf + ((size_t)b * 16 + wave * 4 + (lid >> 4)) * 6;
                     dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = b0; dst[4] = b1; dst[5] = b2;
                 }
             }
@@ -564,6 +668,13 @@ hipError_t launch_skin_k(const RigDev& rig, const CrowdDev& cr, const SkinPlan& 
 
 hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s) {
     if (cr.I == 0 || rig.T == 0) return hipSuccess;
+    // what the kernel's indexing assumes about the plan (checked here, on the host, every launch)
+    if (plan.batch == 0 || plan.range == 0 || plan.range > 256 || plan.range % plan.batch != 0 ||
+        (uint64_t)plan.ranges * plan.range < cr.I || plan.lds_bytes > 64 * 1024 ||
+        plan.tile_chunks == 0 || 8 % plan.tile_chunks != 0 ||
+        (uint64_t)plan.tiles_per_chunk * plan.tile_chunks < rig.T ||
+        (uint64_t)plan.ranges_per_chunk * (8 / plan.tile_chunks) < plan.ranges)
+        return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     if (plan.lds_tiles)
         e = plan.exact ? launch_skin_k<true, true>(rig, cr, plan, s) : launch_skin_k<false, true>(rig, cr, plan, s);
