@@ -75,3 +75,34 @@ def test_c3_avatar_x10000(oracle32):
 
 def test_c5_stress_x1000(oracle32, oracle64):
     run_full(oracle32, "c5", [0, 255, 999], conditioned=True, oracle64=oracle64)
+
+
+def test_instance_range_cap_with_batch_not_dividing_256(oracle32):
+    """70,000 instances x 16 tiles: the per-block instance range reaches its cap of 256, and this
+    rig's batch size (10: 16 joints per tile, no morph targets) does not divide 256 — the range
+    must round DOWN (250), or blocks would index past the kernel's 256-entry instance-order
+    tables (a fault seen once with a diagnostic build).  Sampled instances against the oracle,
+    including the first / last of ranges under the wrong (260) and the right (250) cut."""
+    spec = synth.scaled(synth.tiny_spec(seed=31), nodes=40, joints=32, verts=4096, targets=0, clips=1, keys=4,
+                        joint_spread=6, max_depth=8)
+    rig = synth.make_rig(spec)
+    n = 70000
+    crowd = synth.make_crowd(spec, rig, instances=n)
+    samples = [0, 249, 250, 255, 256, 259, 260, 499, 500, 34999, 69749, 69750, n - 1]
+    with api.Context() as ctx:
+        r = api.Rig(ctx, rig)
+        c = api.Crowd(ctx, r, n)
+        c.set_clocks(crowd.tau, crowd.clip_id)
+        c.evaluate(abi.STAGE_ALL, sync=True)
+        bounds = c.aabbs()
+        assert np.isfinite(bounds).all()
+        desc = rig.to_desc()
+        for i in samples:
+            ref = oracle32.evaluate(rig, crowd.tau[i:i + 1], crowd.clip_id[i:i + 1], desc=desc)
+            assert_equal(c.palette(i, 1)[0], ref.palette_rows()[0], f"[{i}] palette")
+            pos = c.positions(i, 1)[0]
+            assert_close(pos, ref.position[0], f"[{i}] position")
+            assert_close(c.normals(i, 1)[0], ref.normal[0], f"[{i}] normal")
+            assert_equal(bounds[i, 0], pos.min(axis=0), f"[{i}] aabb.min")
+            assert_equal(bounds[i, 1], pos.max(axis=0), f"[{i}] aabb.max")
+        c.close(); r.close()
