@@ -13,8 +13,8 @@
 //   k_pose_wave   one 64-lane wavefront per instance, node matrices in LDS, nodes processed
 //                 level by level (topologically-levelled propagation), palette from LDS.
 //   split path    for rigs whose node table does not fit LDS or whose hierarchy is too deep to
-//                 level-step: k_sample_local (thread per instance x node), k_propagate_lane
-//                 (lane per instance walking the DFS order with the parent kept in registers),
+//                 level-step: k_sample_local (thread per instance x node), k_propagate_quad
+//                 (16 lanes per instance walking the DFS order, the 3x4 product spread over lanes),
 //                 k_palette (thread per instance x joint).
 #include "device_types.hpp"
 
@@ -248,30 +248,70 @@ __global__ __launch_bounds__(256) void k_sample_local(const RigDev rig, const Cr
     store_rows(cr.world + g * 12, l);
 }
 
-// One lane per instance walks the DFS pre-order; the previous node's world matrix stays in
-// registers (in pre-order the parent is usually the previous node), the next local matrix is
-// prefetched, so a 4096-deep chain costs one dependent FMA group per node, not a memory trip.
-__global__ __launch_bounds__(64) void k_propagate_lane(const RigDev rig, const CrowdDev cr) {
-    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= cr.I) return;
-    float* w = cr.world + (size_t)i * rig.N * 12;
-    Rows root;
+// Deep rigs (C5: a 4096-node chain) leave no parallelism across nodes, so the parallelism is taken
+// INSIDE the 3x4 product: 16 lanes per instance (12 used), lane e = row e/4, column e%4 of the
+// current world matrix.  A lane needs its own ROW of the parent's world matrix — the 4 lanes of its
+// DPP quad, fetched with quad broadcasts, no memory — and one COLUMN of the node's local matrix,
+// which does not depend on the chain and is prefetched a chunk of nodes ahead.  The dependent
+// chain per node is 4 DPP moves + 6 float ops; the element order is mul_row()'s, so the result is
+// bit-equal to the level-parallel kernel and to the oracle.
+template <int CTRL>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+constexpr int kPropChunk = 8;  // nodes whose local columns are in registers ahead of the chain
+
+__global__ __launch_bounds__(64) void k_propagate_quad(const RigDev rig, const CrowdDev cr) {
+    const uint32_t lane = threadIdx.x, e = lane & 15;
+    const uint32_t i = blockIdx.x * 4 + (lane >> 4);
+    const bool act = i < cr.I && e < 12;
+    const uint32_t r = e >> 2, c = e & 3;
+    float* w = cr.world + (size_t)(act ? i : 0) * rig.N * 12;  // locals in, worlds out (in place)
     const bool has_root = cr.root != nullptr;
-    if (has_root) root = load_rows(cr.root + (size_t)i * 12);
-    Rows prev;
-    Rows next = load_rows(w);
-    for (uint32_t n = 0; n < rig.N; ++n) {
-        const Rows l = next;
-        if (n + 1 < rig.N) next = load_rows(w + (size_t)(n + 1) * 12);
-        const int32_t p = rig.parent[n];
-        Rows out;
-        if (p < 0) out = has_root ? mul_affine(root, l) : l;
-        else {
-            const Rows pw = (p == (int32_t)n - 1) ? prev : load_rows(w + (size_t)p * 12);
-            out = mul_affine(pw, l);
+    const float root_e = (has_root && act) ? cr.root[(size_t)i * 12 + e] : 0.0f;
+    const uint32_t N = rig.N;
+
+    float l0[kPropChunk], l1[kPropChunk], l2[kPropChunk];  // column c of the chunk's local matrices
+    auto load_chunk = [&](uint32_t base, float (&a0)[kPropChunk], float (&a1)[kPropChunk], float (&a2)[kPropChunk]) {
+#pragma unroll
+        for (int d = 0; d < kPropChunk; ++d) {
+            const uint32_t n = base + d;
+            const bool ok = act && n < N;
+            const float* q = w + (size_t)n * 12 + c;
+            a0[d] = ok ? q[0] : 0.0f;
+            a1[d] = ok ? q[4] : 0.0f;
+            a2[d] = ok ? q[8] : 0.0f;
         }
-        store_rows(w + (size_t)n * 12, out);
-        prev = out;
+    };
+    load_chunk(0, l0, l1, l2);
+    float prev = 0.0f;  // this lane's element of the previous node's world matrix
+    for (uint32_t base = 0; base < N; base += kPropChunk) {
+        float n0[kPropChunk], n1[kPropChunk], n2[kPropChunk];
+        load_chunk(base + kPropChunk, n0, n1, n2);  // past the end: zeros, never used
+#pragma unroll
+        for (int d = 0; d < kPropChunk; ++d) {
+            const uint32_t n = base + d;
+            if (n < N) {  // wave-uniform
+                const int32_t p = rig.parent[n];
+                float pe = prev;
+                bool mul = true;
+                if (p < 0) {
+                    pe = root_e;
+                    mul = has_root;
+                } else if (p != (int32_t)n - 1) {
+                    pe = act ? w[(size_t)p * 12 + e] : 0.0f;  // written earlier by this same lane
+                }
+                const float ax = quad_bcast<0x00>(pe), ay = quad_bcast<0x55>(pe), az = quad_bcast<0xAA>(pe), aw = quad_bcast<0xFF>(pe);
+                float out = (ax * l0[d] + ay * l1[d]) + az * l2[d];
+                if (c == 3) out = out + aw;
+                if (!mul) out = r == 0 ? l0[d] : (r == 1 ? l1[d] : l2[d]);  // root without a root transform: world = local
+                if (act) w[(size_t)n * 12 + e] = out;
+                prev = out;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < kPropChunk; ++d) { l0[d] = n0[d]; l1[d] = n1[d]; l2[d] = n2[d]; }
     }
 }
 
@@ -294,7 +334,7 @@ hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t quirk, Po
     }
     const uint64_t in = (uint64_t)cr.I * rig.N;
     hipLaunchKernelGGL(k_sample_local, dim3((uint32_t)((in + 255) / 256)), dim3(256), 0, s, rig, cr, quirk);
-    hipLaunchKernelGGL(k_propagate_lane, dim3((cr.I + 63) / 64), dim3(64), 0, s, rig, cr);
+    hipLaunchKernelGGL(k_propagate_quad, dim3((cr.I + 3) / 4), dim3(64), 0, s, rig, cr);
     if (rig.J) {
         const uint64_t ij = (uint64_t)cr.I * rig.J;
         hipLaunchKernelGGL(k_palette, dim3((uint32_t)((ij + 255) / 256)), dim3(256), 0, s, rig, cr);

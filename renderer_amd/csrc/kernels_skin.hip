@@ -294,7 +294,7 @@ constexpr uint32_t kSkinThreads = 320;  // 4 compute waves (256 vertices) + 1 lo
 // active morph-pair records) into the other LDS buffer and writes batch k-1's bounds.  One
 // LDS-only barrier per batch hands the buffers over.
 template <bool EXACT, int K, bool LDSPAL>
-__global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
+__global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void k_skin(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
@@ -635,15 +635,23 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : 2)) void k_skin(const R
 }
 
 
-// a14: bounds of one instance = min/max over its tiles' partial bounds (order-independent, exact)
-__global__ __launch_bounds__(256) void k_aabb_reduce(const RigDev rig, const CrowdDev cr) {
-    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= (uint64_t)cr.I * 6) return;
-    const uint32_t i = (uint32_t)(g / 6), c = (uint32_t)(g % 6);
+// a14: bounds of one instance = min/max over its tiles' partial bounds (order-independent, exact).
+// One 192-thread block per instance: an instance's partials are 6*T contiguous floats, thread t owns
+// component t % 6 and strides by 192 (a multiple of 6), so every load is coalesced.
+constexpr uint32_t kAabbThreads = 192;
+__global__ __launch_bounds__(kAabbThreads) void k_aabb_reduce(const RigDev rig, const CrowdDev cr) {
+    __shared__ float part[kAabbThreads];
+    const uint32_t i = blockIdx.x, t = threadIdx.x, c = t % 6;
+    const float* src = cr.aabb_part + (size_t)i * rig.T * 6;
+    const uint32_t n = rig.T * 6;
     float r = c < 3 ? __builtin_inff() : -__builtin_inff();
-    const float* src = cr.aabb_part + (size_t)i * rig.T * 6 + c;
-    for (uint32_t t = 0; t < rig.T; ++t) r = c < 3 ? fminf(r, src[(size_t)t * 6]) : fmaxf(r, src[(size_t)t * 6]);
-    cr.aabb[g] = r;
+    for (uint32_t e = t; e < n; e += kAabbThreads) r = c < 3 ? fminf(r, src[e]) : fmaxf(r, src[e]);
+    part[t] = r;
+    __syncthreads();
+    if (t < 6) {
+        for (uint32_t q = t + 6; q < kAabbThreads; q += 6) r = c < 3 ? fminf(r, part[q]) : fmaxf(r, part[q]);
+        cr.aabb[(size_t)i * 6 + t] = r;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fill_mw(float* mw, const float* defaults, uint64_t total, uint32_t M) {
@@ -702,8 +710,7 @@ void debug_dump_stamps() {
 
 hipError_t launch_aabb_reduce(const RigDev& rig, const CrowdDev& cr, hipStream_t s) {
     if (cr.I == 0) return hipSuccess;
-    const uint64_t n = (uint64_t)cr.I * 6;
-    hipLaunchKernelGGL(k_aabb_reduce, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, rig, cr);
+    hipLaunchKernelGGL(k_aabb_reduce, dim3(cr.I), dim3(kAabbThreads), 0, s, rig, cr);
     return hipGetLastError();
 }
 
