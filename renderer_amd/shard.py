@@ -24,11 +24,13 @@ def padded_count(instances: int, world: int) -> int:
 
 def all_gather_rows(local, instances: int, world: int, group=None):
     """All-gather per-instance rows (`local`: [n_local, ...] torch tensor on any device) into
-    [instances, ...], dropping the padding of the last rank.  world == 1: returns `local`."""
-    if world == 1:
-        return local
+    [instances, ...], dropping the padding of the last rank.  world == 1 without a process group:
+    returns `local` (with one, the collective still runs — the single-GPU rehearsal of the N>1 path)."""
     import torch
     import torch.distributed as dist
+
+    if world == 1 and not dist.is_initialized():
+        return local
 
     per = padded_count(instances, world)
     if local.shape[0] != per:
