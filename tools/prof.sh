@@ -3,6 +3,7 @@
 # usage: tools/prof.sh <outdir-under-gpurun_out> [bench args...]
 set -u
 OUT=gpurun_out/$1; shift
+rm -rf $OUT
 ARGS="$@"
 mkdir -p $OUT
 export TMPDIR=/tmp
