@@ -1,0 +1,204 @@
+"""Native .glb loader + scene flattener (renderer_amd/host).  A synthetic rig
+is serialised as a binary glTF with shuffled node indices (tests/glb_writer.py), loaded back by
+the C++ loader and flattened; the flat rig must equal the original — node ORDER bit-exact (DFS
+pre-order rebuilt from `children`), joints, keyframes, vertex data — and evaluate identically.
+The loader follows the reference's conventions (renderer-asset/src/loader/gltf/mod.rs); its
+quirks are tested one by one below.  PARITY UNPINNED: the reference loader cannot run here."""
+import json
+import struct
+
+import numpy as np
+import pytest
+
+from renderer_amd import abi, api, hostlib, synth
+from tests import helpers
+from tests.glb_writer import write_glb
+
+
+def dense_target(rig, t, attr, w):
+    a = getattr(t, attr)
+    v = rig.vertex_count
+    if a is None:
+        return np.zeros((v, w), np.float32)
+    if t.indices is None:
+        return np.asarray(a, np.float32).reshape(v, -1)[:, :w]
+    d = np.zeros((v, w), np.float32)
+    d[t.indices] = np.asarray(a, np.float32).reshape(len(t.indices), -1)[:, :w]
+    return d
+
+
+def assert_same_rig(a, b, weights_quantised=False):
+    assert np.array_equal(a.parent, b.parent)
+    has_a = a.has_matrix if a.has_matrix is not None else np.zeros(a.node_count, np.uint8)
+    has_b = b.has_matrix if b.has_matrix is not None else np.zeros(b.node_count, np.uint8)
+    assert np.array_equal(has_a, has_b)
+    trs = has_a == 0
+    for k in ("translation", "rotation", "scale"):
+        assert np.array_equal(getattr(a, k)[trs].view(np.uint32), getattr(b, k)[trs].view(np.uint32)), k
+    if has_a.any():
+        assert np.array_equal(a.matrix[has_a != 0], b.matrix[has_b != 0])
+    assert np.array_equal(a.joint_node, b.joint_node)
+    if a.inverse_bind is not None:
+        assert np.array_equal(a.inverse_bind, b.inverse_bind)
+    assert np.array_equal(a.position, b.position) and np.array_equal(a.normal, b.normal)
+    assert np.array_equal(a.tangent[:, :3], b.tangent[:, :3])
+    assert a.set_count == b.set_count
+    for k in range(a.set_count):
+        assert np.array_equal(a.joints[k], b.joints[k])
+        if weights_quantised:
+            q = np.round(np.clip(a.weights[k], 0, 1) * 65535.0).astype(np.uint16)
+            assert np.array_equal((q.astype(np.float32) / np.float32(65535.0)), b.weights[k])  # u16 / 65535 (loader/gltf/mod.rs:343-347)
+        else:
+            assert np.array_equal(a.weights[k], b.weights[k])
+    assert len(a.clips) == len(b.clips)
+    for ca, cb in zip(a.clips, b.clips):
+        assert len(ca) == len(cb)
+        for x, y in zip(ca, cb):
+            assert (x.target_node, x.path, x.interpolation) == (y.target_node, y.path, y.interpolation)
+            assert np.array_equal(x.times, y.times)
+            assert np.array_equal(np.asarray(x.values).reshape(-1), np.asarray(y.values).reshape(-1))
+    assert a.target_count == b.target_count
+    for ta, tb in zip(a.targets, b.targets):
+        assert np.array_equal(dense_target(a, ta, "position", 3), dense_target(b, tb, "position", 3))
+        assert np.array_equal(dense_target(a, ta, "normal", 3), dense_target(b, tb, "normal", 3))
+        assert np.array_equal(dense_target(a, ta, "tangent", 3), dense_target(b, tb, "tangent", 3))
+
+
+SPECS = {
+    "tiny": synth.tiny_spec(seed=51, matrix_nodes=2),
+    "two_sets_sparse_targets": synth.tiny_spec(seed=52, sets=2, target_mode="sparse", target_frac=0.3, targets=4),
+    "c1_shape": synth.CONFIGS["c1"],
+    "c3_shape": synth.scaled(synth.CONFIGS["c3"], verts=1200, targets=6, keys=5),
+}
+
+
+@pytest.mark.parametrize("name", list(SPECS))
+def test_round_trip_through_glb(name, oracle32):
+    spec = SPECS[name]
+    rig = synth.make_rig(spec)
+    glb, perm = write_glb(rig, seed=7)
+    loaded, order, lengths = hostlib.load_glb(glb)
+    # node ordering: flat node k is glTF node perm[k] — the flattener rebuilt the DFS pre-order
+    assert np.array_equal(order, perm.astype(np.uint32))
+    assert_same_rig(rig, loaded)
+    for c in range(len(rig.clips)):
+        assert lengths[c] == np.float32(rig.clip_length(c))
+    info = api.validate_rig(loaded)
+    assert (info.node_count, info.joint_count, info.vertex_count) == (rig.node_count, rig.joint_count, rig.vertex_count)
+    crowd = synth.make_crowd(spec, rig, instances=3)
+    a = helpers.run_oracle(oracle32, rig, crowd)
+    b = helpers.run_oracle(oracle32, loaded, crowd)
+    for k in a:
+        helpers.assert_equal(np.asarray(a[k]).view(np.uint32), np.asarray(b[k]).view(np.uint32), k)
+
+
+def test_u8_joints_and_u16_weights_follow_the_reference_constants():
+    spec = synth.tiny_spec(seed=53)
+    rig = synth.make_rig(spec)
+    glb, _ = write_glb(rig, seed=1, joints_u8=True, weights_u16=True, interleave=False)
+    loaded, _, _ = hostlib.load_glb(glb)
+    assert loaded.joints[0].dtype == np.uint16
+    assert_same_rig(rig, loaded, weights_quantised=True)
+
+
+def test_missing_inverse_bind_matrices_mean_identity():
+    spec = synth.tiny_spec(seed=54)
+    rig = synth.make_rig(spec)
+    glb, _ = write_glb(rig, seed=2, omit_ibm=True)
+    loaded, _, _ = hostlib.load_glb(glb)
+    assert loaded.inverse_bind is None
+
+
+def _edit(glb, fn):
+    """re-pack a GLB after editing its JSON document"""
+    jl = struct.unpack_from("<I", glb, 12)[0]
+    doc = json.loads(glb[20:20 + jl].decode())
+    rest = glb[20 + jl:]
+    fn(doc)
+    js = json.dumps(doc, separators=(",", ":")).encode()
+    js += b" " * (-len(js) % 4)
+    return struct.pack("<III", 0x46546C67, 2, 12 + 8 + len(js) + len(rest)) + struct.pack("<II", len(js), 0x4E4F534A) + js + rest
+
+
+def _expect(glb, code, needle):
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.load_glb(glb)
+    assert e.value.code == code and needle in e.value.message, e.value
+
+
+def test_errors_where_the_reference_panics():
+    spec = synth.tiny_spec(seed=55)
+    rig = synth.make_rig(spec)
+    glb, _ = write_glb(rig, seed=3)
+    _expect(b"nope" + glb[4:], abi.E_INVALID, "magic")
+    _expect(_edit(glb, lambda d: d["meshes"][0]["primitives"][0]["attributes"].pop("POSITION")), abi.E_INVALID, "No positions")
+    _expect(_edit(glb, lambda d: d["animations"][0]["channels"][0]["target"].update(path="weights")), abi.E_INVALID, "todo!()")
+    _expect(_edit(glb, lambda d: d["accessors"][d["meshes"][0]["primitives"][0]["attributes"]["WEIGHTS_0"]].update(componentType=5122)),
+            abi.E_INVALID, "signed normalised")
+    _expect(_edit(glb, lambda d: d["bufferViews"][0].update(byteOffset=10 ** 9)), abi.E_RANGE, "past its buffer")
+    _expect(_edit(glb, lambda d: d["meshes"][0]["primitives"][0]["targets"][0].update(
+        TANGENT=d["meshes"][0]["primitives"][0]["targets"][0]["POSITION"])), abi.E_INVALID, "BadAccessorDimensions")
+    _expect(_edit(glb, lambda d: d["meshes"][0]["primitives"][0].update(mode=6)), abi.E_INVALID, "UnsupportedPrimitiveMode")
+    # an unknown animation target node is caught by the flattener
+    _expect(_edit(glb, lambda d: d["animations"][0]["channels"][0]["target"].update(node=10 ** 6)), abi.E_RANGE, "unknown node")
+
+
+def test_accessor_without_buffer_view_is_count_zero_bytes():
+    # the reference yields `count` zero BYTES (not count x item size): a VEC3 float accessor of count 12
+    # becomes 12 bytes = one zero vertex (loader/gltf/mod.rs:241-245)
+    spec = synth.tiny_spec(seed=56, targets=0)
+    rig = synth.make_rig(spec)
+    glb, _ = write_glb(rig, seed=4, interleave=False)
+
+    def strip(d):
+        acc = d["accessors"][d["meshes"][0]["primitives"][0]["attributes"]["NORMAL"]]
+        acc.pop("bufferView"); acc["count"] = 12
+    with pytest.raises(hostlib.HostError) as e:   # 1 normal for 64 vertices: the flattener refuses the mismatch
+        hostlib.load_glb(_edit(glb, strip))
+    assert "attribute lengths differ" in e.value.message
+
+
+def test_missing_normal_and_tangent_are_generated_like_the_reference():
+    # tangent := normalised sum of unit face normals, w = 1; normal := that tangent's xyz
+    # (tangent.rs:15-58, loader/gltf/mod.rs:1086-1089)
+    spec = synth.tiny_spec(seed=57, targets=0, verts=6)
+    rig = synth.make_rig(spec)
+    rig.position = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 1, 1], [1, 0, 1]], np.float32)
+    glb, _ = write_glb(rig, seed=5, interleave=False)
+
+    def strip(d):
+        a = d["meshes"][0]["primitives"][0]["attributes"]
+        a.pop("NORMAL"); a.pop("TANGENT")
+    loaded, _, _ = hostlib.load_glb(_edit(glb, strip))
+    # triangle (p0,p1,p2): (p2-p1) x (p0-p1) = (-1,1,0) x (-1,0,0) = (0,0,1)
+    assert loaded.tangent[:3, :3].tolist() == [[0, 0, 1]] * 3 and loaded.tangent[:, 3].tolist() == [1.0] * 6
+    assert np.array_equal(loaded.normal, loaded.tangent[:, :3])
+    want = hostlib.calculate_tangent(4, rig.position)
+    assert np.array_equal(loaded.tangent[:, :3], want)
+
+
+def test_calculate_tangent_indexed_accumulates_per_vertex():
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    idx = np.array([0, 1, 2, 0, 3, 1], np.uint32)
+    t = hostlib.calculate_tangent(4, pos, idx)
+    # faces: (0,1,2) -> (0,0,1); (0,3,1): (p1-p3) x (p0-p3) = (1,0,-1) x (0,0,-1) = (0,1,0)
+    s = np.float32(1.0) / np.sqrt(np.float32(2.0))
+    np.testing.assert_allclose(t[0], [0, s, s], rtol=1e-7)
+    assert t[2].tolist() == [0, 0, 1] and t[3].tolist() == [0, 1, 0]
+    with pytest.raises(hostlib.HostError):
+        hostlib.calculate_tangent(3, pos)   # TriangleStrip: todo!() in the reference
+    assert np.isnan(hostlib.calculate_tangent(0, pos)).all()   # points: zero vectors normalised -> NaN, as the reference
+
+
+@pytest.mark.gpu
+def test_loaded_glb_evaluates_on_the_gpu(oracle32):
+    spec = SPECS["c3_shape"]
+    rig = synth.make_rig(spec)
+    glb, _ = write_glb(rig, seed=9)
+    loaded, _, _ = hostlib.load_glb(glb)
+    crowd = synth.make_crowd(spec, rig, instances=5)
+    got = helpers.run_gpu(loaded, crowd, exact_arithmetic=1)
+    ref = helpers.run_oracle(oracle32, rig, crowd)
+    helpers.assert_equal(got["key_index"], ref["key_index"], "key_index")
+    for k in ("world", "palette", "position", "normal", "tangent", "aabb"):
+        helpers.assert_equal(got[k].view(np.uint32), np.asarray(ref[k]).view(np.uint32), k)
