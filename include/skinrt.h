@@ -91,7 +91,9 @@ typedef struct skinrt_config {
     /* 0: choose per rig; 1: wavefront-per-instance pose kernel; 2: split pose kernels
      *    (sample / lane-per-instance propagate / palette) used for very deep or large rigs. */
     uint32_t pose_path;
-    uint32_t reserved[1];
+    /* 0: choose per tile; 1: only the loader-wave skinning kernel (the self-staging kernel, used
+     *    for tiles with at most 21 joints and rigs with at most 2 weight sets, is switched off). */
+    uint32_t skin_path;
 } skinrt_config;
 
 /* ---- flat rig ("loader output", SURVEY.md §8a rows a1,a5-a8,a11,a13) ---------------- */

@@ -36,7 +36,7 @@ class Config(C.Structure):
         ("reference_limits", C.c_uint32),
         ("exact_arithmetic", C.c_uint32),
         ("pose_path", C.c_uint32),
-        ("reserved", C.c_uint32 * 1),
+        ("skin_path", C.c_uint32),
     ]
 
 

@@ -94,7 +94,7 @@ def _check(rc: int):
 
 
 def make_config(device: int = 0, cubic_quirk: int = 1, normalize_outputs: int = 0, reference_limits: int = 0,
-                exact_arithmetic: int = 0, pose_path: int = 0) -> Config:
+                exact_arithmetic: int = 0, pose_path: int = 0, skin_path: int = 0) -> Config:
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.device = device
@@ -103,6 +103,7 @@ def make_config(device: int = 0, cubic_quirk: int = 1, normalize_outputs: int = 
     cfg.reference_limits = reference_limits
     cfg.exact_arithmetic = exact_arithmetic
     cfg.pose_path = pose_path
+    cfg.skin_path = skin_path
     return cfg
 
 

@@ -147,6 +147,21 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
     p.tiles_per_chunk = (T + p.tile_chunks - 1) / p.tile_chunks;
     const uint32_t rcs = 8 / p.tile_chunks;
     p.ranges_per_chunk = (std::max<uint32_t>(1, p.ranges) + rcs - 1) / rcs;
+    // ---- self-staging kernel (k_skin2): 4 waves per block, every wave stages its own palette ring
+    // and morph slots, 5 blocks (20 compute waves) per CU -> a block must stay under 32 KiB of LDS
+    p.kinds = (r.tile_kind_count[0] ? 1u : 0u) | (r.tile_kind_count[1] ? 2u : 0u) | (r.tile_kind_count[2] ? 4u : 0u);
+    p.v2 = (cfg.skin_path == 0 && r.K <= 2 && r.tile_kind_count[2] > 0) ? 1 : 0;
+    {
+        p.jt2_shift = std::min<uint32_t>(p.jt_shift, 5);  // kind-2 tiles have at most 21 joints
+        const uint32_t per_wave = kSkin2PalRing * (96u << p.jt2_shift) + (r.M ? kMorphSlots * kMorphWaveFloats * 4 : 0);
+        const uint32_t tables = kSkin2Range * (16 + 4 + 2) + p.max_pairs * 16 + 64;
+        p.lds_bytes2 = tables + 4 * per_wave;
+        if (p.lds_bytes2 > 64 * 1024) p.v2 = 0;
+        uint64_t r2 = ((uint64_t)I * std::max<uint32_t>(1, r.T) + want_blocks - 1) / want_blocks;
+        p.range2 = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(r2, 1), kSkin2Range);
+        p.ranges2 = I ? (I + p.range2 - 1) / p.range2 : 0;
+        p.ranges_per_chunk2 = (std::max<uint32_t>(1, p.ranges2) + rcs - 1) / rcs;
+    }
     p.exact = cfg.exact_arithmetic ? 1 : 0;
     p.normalize = cfg.normalize_outputs ? 1 : 0;
     p.aabb = 0;
@@ -185,6 +200,7 @@ int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx) {
     if (!config || !out_ctx) return fail(SKINRT_E_INVALID, "skinrt_init: NULL argument");
     if (config->struct_size != sizeof(skinrt_config)) return fail(SKINRT_E_INVALID, "skinrt_config.struct_size mismatch");
     if (config->pose_path > 2) return fail(SKINRT_E_INVALID, "skinrt_config.pose_path must be 0, 1 or 2");
+    if (config->skin_path > 1) return fail(SKINRT_E_INVALID, "skinrt_config.skin_path must be 0 or 1");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (config->device < 0 || config->device >= count) return fail(SKINRT_E_DEVICE, "no such HIP device");
@@ -295,7 +311,7 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
         {&c->tau, I * 4}, {&c->clip, I * 4}, {&c->mw, I * h.M * 4}, {&c->root, I * 48},
         {&c->world, I * h.N * 48}, {&c->palette, I * h.J * 96}, {&c->keyidx, I * h.Cmax * 4},
         {&c->pos, I * h.V * 12}, {&c->nrm, I * h.V * 12}, {&c->tan, I * h.V * 12},
-        {&c->aabb_part, I * h.T * 24}, {&c->aabb, I * 24},
+        {&c->aabb_part, I * h.T * 4 * 24}, {&c->aabb, I * 24},  // bounds per (instance, tile, wave)
     };
     for (auto& it : plan) {
         hipError_t e = it.b->alloc(it.n);

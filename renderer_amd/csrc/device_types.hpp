@@ -70,7 +70,15 @@ struct SkinPlan {
     uint32_t exact;     // 1: contraction-free arithmetic (bit-equal to the fp32 oracle)
     uint32_t normalize; // shader.wgsl:217-218 variant
     uint32_t aabb;      // write per-(instance,tile) bounds
-    uint32_t debug;     // SKINRT_DEBUG ablation bits (timing experiments only)
+    uint32_t debug;     // unused
+    // self-staging kernel (k_skin2): tiles of kind 2 when v2 != 0
+    uint32_t v2;                 // 1: kind-2 tiles go to k_skin2, 0: to k_skin
+    uint32_t range2;             // instances per k_skin2 block (<= 128)
+    uint32_t ranges2;            // ceil(I / range2)
+    uint32_t ranges_per_chunk2;  // ceil(ranges2 / (8 / tile_chunks))
+    uint32_t lds_bytes2;         // dynamic LDS per k_skin2 block
+    uint32_t kinds;              // bit k set: the rig has tiles of kind k
+    uint32_t jt2_shift;          // log2 of k_skin2's padded tile joint-list length (<= 5)
 };
 
 enum PosePath : uint32_t { kPoseWave = 0, kPoseSplit = 1 };

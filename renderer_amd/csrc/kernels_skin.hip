@@ -117,9 +117,8 @@ struct GlobalPal {
 // Scalar v_fma_f32 on purpose (the file is built with -fno-slp-vectorize): on gfx950 a
 // v_pk_fma_f32 costs more issue time than the two v_fma_f32 it replaces.
 template <bool EXACT, int K, class Pal>
-__device__ __forceinline__ void skin_position(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
-                                              const float (&p)[3], float (&op)[3]) {
-    float S[12];  // rows of the blended 3x4
+__device__ __forceinline__ void blend_position(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
+                                               float (&S)[12]) {  // rows of the blended 3x4
 #pragma unroll
     for (int a = 0; a < 4 * K; ++a) {
         const f4* e = pal.entry(li[a]);
@@ -130,6 +129,9 @@ __device__ __forceinline__ void skin_position(const Pal pal, const float (&w)[4 
         // two influences' rows in flight at a time: bounds the live registers (5 waves per SIMD)
         if ((a & 1) && a + 1 < 4 * K) __builtin_amdgcn_sched_barrier(0);
     }
+}
+template <bool EXACT>
+__device__ __forceinline__ void apply_position(const float (&S)[12], const float (&p)[3], float (&op)[3]) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         float s = mul_nc(S[4 * r], p[0]);
@@ -140,10 +142,8 @@ __device__ __forceinline__ void skin_position(const Pal pal, const float (&w)[4 
 }
 
 template <bool EXACT, int K, class Pal>
-__device__ __forceinline__ void skin_normal(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
-                                            const float (&n)[3], const float (&t)[3], bool normalize,
-                                            float (&on)[3], float (&ot)[3]) {
-    float Nm[9];  // rows of the blended normal matrix
+__device__ __forceinline__ void blend_normal(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
+                                             float (&Nm)[9]) {  // rows of the blended normal matrix
 #pragma unroll
     for (int a = 0; a < 4 * K; ++a) {
         const f4* e = pal.entry(li[a]);
@@ -154,6 +154,10 @@ __device__ __forceinline__ void skin_normal(const Pal pal, const float (&w)[4 * 
         for (int x = 0; x < 9; ++x) Nm[x] = a == 0 ? mul_nc(w[0], q[x]) : madd<EXACT>(w[a], q[x], Nm[x]);
         if ((a & 1) && a + 1 < 4 * K) __builtin_amdgcn_sched_barrier(0);
     }
+}
+template <bool EXACT>
+__device__ __forceinline__ void apply_normal(const float (&Nm)[9], const float (&n)[3], const float (&t)[3], bool normalize,
+                                             float (&on)[3], float (&ot)[3]) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         float a = mul_nc(Nm[3 * r], n[0]);
@@ -276,9 +280,17 @@ __device__ __forceinline__ void skin_store(const Pal pal, const float (&w)[4 * K
     // stores take the SGPR-base + VGPR-offset form and share one offset register.  Left to itself
     // the compiler hoists three 64-bit per-lane pointers out of the instance loop and spills them.
     float on[3], ot[3];
-    skin_position<EXACT, K>(pal, w, li, p, op);
+    {
+        float S[12];
+        blend_position<EXACT, K>(pal, w, li, S);
+        apply_position<EXACT>(S, p, op);
+    }
     if (valid) store3(out.pos + obase, olb, op);
-    skin_normal<EXACT, K>(pal, w, li, n, t, normalize, on, ot);
+    {
+        float Nm[9];
+        blend_normal<EXACT, K>(pal, w, li, Nm);
+        apply_normal<EXACT>(Nm, n, t, normalize, on, ot);
+    }
     if (valid) {
         store3(out.nrm + obase, olb, on);
         store3(out.tan + obase, olb, ot);
@@ -311,7 +323,10 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
     if (tile >= rig.T || rng >= plan.ranges) return;
     // tiles whose joint list fits LDS are skinned by the LDSPAL=true launch, the rest (rare: no
     // joint locality) by the LDSPAL=false launch that gathers the palette from L2
-    if ((rig.tile_lds[tile] != 0) != LDSPAL) return;
+    {
+        const uint32_t kind = rig.tile_lds[tile];  // 2: short joint list (k_skin2's tiles unless switched off)
+        if (LDSPAL ? !(kind == 1 || (kind == 2 && !plan.v2)) : kind != 0) return;
+    }
     const uint32_t i0 = rng * plan.range;
     const uint32_t i1 = min(cr.I, i0 + plan.range);
     const uint32_t JTP = 1u << plan.jt_shift;
@@ -486,7 +501,10 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
                 const float* src = ab_s + buf * ab_buf + (size_t)b * 16 * 6 + c;
                 float r = src[0];
                 for (int q = 1; q < 16; ++q) r = c < 3 ? fminf(r, src[q * 6]) : fmaxf(r, src[q * 6]);
-                cr.aabb_part[((size_t)inst_at(pos0 + b) * rig.T + tile) * 6 + c] = r;
+                // bounds are kept per (instance, tile, wave) for k_skin2; this kernel has one value per
+                // tile and writes it to all four entries (min / max are idempotent)
+                float* dst = cr.aabb_part + ((size_t)inst_at(pos0 + b) * rig.T + tile) * 24 + c;
+                dst[0] = r; dst[6] = r; dst[12] = r; dst[18] = r;
             }
         };
 
@@ -635,6 +653,313 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
 }
 
 
+// =====================================================================================================
+// k_skin2 — the self-staging variant.  No loader wave and no batch barrier: a block is 4 independent
+// compute waves (64 vertices each) and every wave stages what it needs itself with LDS-DMA, which
+// has no register destination and therefore needs no wait until the data is used:
+//   * the palette rows of the tile's joints for instance pos+2 are requested at the top of
+//     instance pos into the wave's own ring of 3 palette slots;
+//   * the morph pairs of instance pos+1 are requested in the middle of instance pos (as in k_skin).
+// All waits are COUNTED (vmcnt is in issue order, loads and stores alike): every instance issues at
+// least `spi` stores, so "palette of this instance has landed" is s_waitcnt vmcnt(2 * spi), and the
+// stores of the last two instances stay in flight.  With no loader the block is 256 threads, five
+// blocks = 20 compute waves per CU instead of 16 (throughput follows the number of compute waves).
+// Per-block tables (instance order, headers with the first two active pairs' weights) are built
+// once in the prologue, before any store exists.  Tiles with more than 21 joints (their palette
+// pieces do not fit two DMA instructions) and rigs with 3-4 weight sets stay on k_skin.
+
+#define SKINRT_GLDS_AT(VOFF, GBASE, LDSB)                                                               \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                       \
+                 : : "v"(VOFF), "s"(GBASE), "s"(LDSB) : "memory")
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+// wait until at most `n` vector-memory operations of this wave are outstanding (n: wave-uniform)
+__device__ __forceinline__ void wait_vmcnt_dyn(uint32_t n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        default: wait_vmcnt<0>(); break;
+    }
+}
+
+// min / max of six values over the whole wave, continuing row_minmax6: result in lane 63
+__device__ __forceinline__ void wave_minmax6(float& a0, float& a1, float& a2, float& b0, float& b1, float& b2) {
+    row_minmax6(a0, a1, a2, b0, b1, b2);
+#define SKINRT_DPP_BCAST(CTRL, MASK)                                                    \
+    asm volatile("s_nop 1\n\t"                                                          \
+                 "v_min_f32_dpp %0, %0, %0 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t" \
+                 "v_min_f32_dpp %1, %1, %1 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t" \
+                 "v_min_f32_dpp %2, %2, %2 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t" \
+                 "v_max_f32_dpp %3, %3, %3 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t" \
+                 "v_max_f32_dpp %4, %4, %4 " CTRL " row_mask:" MASK " bank_mask:0xf\n\t" \
+                 "v_max_f32_dpp %5, %5, %5 " CTRL " row_mask:" MASK " bank_mask:0xf"     \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2))
+    SKINRT_DPP_BCAST("row_bcast:15", "0xa");  // rows 1 and 3 take in lane 15 of rows 0 and 2
+    SKINRT_DPP_BCAST("row_bcast:31", "0xc");  // rows 2 and 3 take in lane 31: lane 63 holds all four rows
+#undef SKINRT_DPP_BCAST
+}
+
+constexpr uint32_t kSkin2Threads = 256;
+
+template <bool EXACT, int K>
+__global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
+    extern __shared__ float4 smem[];
+    constexpr uint32_t TV = kTileVerts;
+    constexpr int W = 4 * K;
+    constexpr uint32_t L = kSkin2PalLook, R = kSkin2PalRing;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t xcd = blockIdx.x & 7, kblk = blockIdx.x >> 3;
+    const uint32_t tc = xcd % plan.tile_chunks, rc = xcd / plan.tile_chunks;
+    const uint32_t tile = tc * plan.tiles_per_chunk + kblk % plan.tiles_per_chunk;
+    const uint32_t rng = rc * plan.ranges_per_chunk2 + kblk / plan.tiles_per_chunk;
+    if (tile >= rig.T || rng >= plan.ranges2) return;
+    if (rig.tile_lds[tile] != 2) return;  // other tiles: k_skin
+    const uint32_t i0 = rng * plan.range2;
+    const uint32_t i1 = min(cr.I, i0 + plan.range2);
+    const uint32_t nin = i1 - i0;  // <= kSkin2Range
+    const uint32_t JTP = 1u << plan.jt2_shift;
+    const uint32_t M = rig.M;
+    // LDS: block tables, then per wave {palette ring, morph slots}
+    uint4* hdr_s = reinterpret_cast<uint4*>(smem);                              // [128] instance headers, processing order
+    uint32_t* mask_s = reinterpret_cast<uint32_t*>(hdr_s + kSkin2Range);        // [128] active-pair mask per instance-in-range
+    uint16_t* perm_s = reinterpret_cast<uint16_t*>(mask_s + kSkin2Range);       // [128] processing order
+    MorphPair* pairs_s = reinterpret_cast<MorphPair*>(perm_s + kSkin2Range + 32);  // [max_pairs] (+32: keeps 16-byte alignment)
+    float* wave_s = reinterpret_cast<float*>(pairs_s + plan.max_pairs);
+    const uint32_t pal_slot_f = JTP * 24;                                       // floats per palette slot
+    const uint32_t per_wave_f = R * pal_slot_f + (M ? kMorphSlots * kMorphWaveFloats : 0u);
+    float* pal_ring = wave_s + (size_t)wave * per_wave_f;                       // [R][JTP][6] f4
+    float* my_slots = pal_ring + R * pal_slot_f;                                // [kMorphSlots][576]
+
+    const uint32_t pbeg = rig.tile_pair_start[tile];
+    const uint32_t np = rig.tile_pair_start[tile + 1] - pbeg;
+    const uint32_t jstart = rig.tile_joint_start[tile];
+    const uint32_t jcnt = rig.tile_joint_start[tile + 1] - jstart;  // <= 21
+    const bool exact_mask = np <= 32;
+
+    // ---------------- block prologue (all 256 threads; no store has been issued yet) ----------------
+    for (uint32_t c = tid; c < np; c += kSkin2Threads) pairs_s[c] = rig.pairs[pbeg + c];
+    __syncthreads();
+    // active-pair mask of instance-in-range `tid` (bit min(q, 31) = pair q has a non-zero weight)
+    uint32_t my_mask = 0xffffffffu;  // padding sorts last
+    if (tid < kSkin2Range) {
+        if (tid < nin) {
+            my_mask = 0;
+            const float* mwg = cr.mw + (size_t)(i0 + tid) * M;
+            for (uint32_t q = 0; q < np; ++q)
+                if (mwg[pairs_s[q].target] != 0.0f) my_mask |= 1u << min(q, 31u);
+        }
+        mask_s[tid] = my_mask;
+    }
+    __syncthreads();
+    // processing order: equal masks become neighbours (rank sort on distinct (mask, index) keys)
+    if (tid < kSkin2Range) {
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < kSkin2Range; j += 4) {
+            const uint4 mj = *reinterpret_cast<const uint4*>(mask_s + j);
+            rank += (mj.x < my_mask || (mj.x == my_mask && j + 0 < tid)) ? 1u : 0u;
+            rank += (mj.y < my_mask || (mj.y == my_mask && j + 1 < tid)) ? 1u : 0u;
+            rank += (mj.z < my_mask || (mj.z == my_mask && j + 2 < tid)) ? 1u : 0u;
+            rank += (mj.w < my_mask || (mj.w == my_mask && j + 3 < tid)) ? 1u : 0u;
+        }
+        perm_s[rank] = (uint16_t)tid;
+    }
+    __syncthreads();
+    // header of the instance at position `tid`:
+    //   x = active pairs (0xff: unknown, more than 32 pairs in the tile) | reload << 8 | fast << 9 |
+    //       first active pair << 16 | second << 24;  y = instance;  z, w = weights of those two pairs
+    // reload: the slots hold another set (its predecessor's mask differs); fast: 1 or 2 active
+    // pairs, both dense -> this header and the slots are all the instance needs.
+    if (tid < nin) {
+        const uint32_t k = perm_s[tid];
+        const uint32_t m = mask_s[k];
+        const uint32_t prev = tid ? mask_s[perm_s[tid - 1]] : ~m;
+        const uint32_t inst = i0 + k;
+        uint32_t na = exact_mask ? (uint32_t)__popc(m) : (m ? 0xffu : 0u);
+        if (SKINRT_ABLATE & 4) na = 0;
+        uint32_t q1 = 0, q2 = 0, fast = 0;
+        float w1 = 0.0f, w2 = 0.0f;
+        if (exact_mask && na >= 1) {
+            q1 = (uint32_t)__ffs((int)m) - 1;
+            const uint32_t m2 = m & (m - 1);
+            q2 = m2 ? (uint32_t)__ffs((int)m2) - 1 : q1;
+            const MorphPair p1 = pairs_s[q1], p2 = pairs_s[q2];
+            w1 = cr.mw[(size_t)inst * M + p1.target];
+            w2 = cr.mw[(size_t)inst * M + p2.target];
+            fast = (kMorphSlots >= 2 && na <= 2 && p1.dense && (na == 1 || p2.dense)) ? 1u : 0u;
+        }
+        const uint32_t reload = (m != prev || !exact_mask) ? 1u : 0u;
+        hdr_s[tid] = make_uint4(na | (reload << 8) | (fast << 9) | (q1 << 16) | (q2 << 24), inst,
+                                __float_as_uint(w1), __float_as_uint(w2));
+    }
+    // this thread's vertex
+    const uint32_t v = tile * TV + tid;
+    const bool valid = v < rig.V;
+    float p0[3], n0[3], t0[3], w[W];
+    uint32_t li[W];
+    {
+        const float* b = rig.base + (size_t)tile * 9 * TV + tid;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { p0[e] = b[e * TV]; n0[e] = b[(3 + e) * TV]; t0[e] = b[(6 + e) * TV]; }
+        const float* wt = rig.wts + (size_t)tile * W * TV + tid;
+        const uint16_t* lp = rig.lidx + (size_t)tile * W * TV + tid;
+#pragma unroll
+        for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
+    }
+    // palette pieces this lane moves: piece c = (list position c / 6, 16-byte quarter c % 6), c = lane and lane + 64
+    const uint32_t npieces = jcnt * 6;  // <= 126
+    uint32_t joff0 = 0, joff1 = 0;      // byte offsets inside one instance's palette
+    if (lane < npieces) joff0 = (rig.tile_joints[jstart + lane / 6] * 6 + lane % 6) * 16;
+    if (lane + 64 < npieces) joff1 = (rig.tile_joints[jstart + (lane + 64) / 6] * 6 + (lane + 64) % 6) * 16;
+    const Outputs out{cr.pos, cr.nrm, cr.tan};
+    const uint32_t olb = v * 12;
+    const bool normalize = plan.normalize != 0;
+    const uint32_t wave_valid = __builtin_amdgcn_readfirstlane(__ballot(valid) != 0ull ? 1u : 0u);
+    // stores this wave issues per instance: position / normal / tangent (none if the wave holds no
+    // real vertex), plus two for its bounds
+    const uint32_t spi = (wave_valid ? 3u : 0u) + (plan.aabb ? 2u : 0u);
+    const char* pal_g = reinterpret_cast<const char*>(cr.palette);
+    const size_t pal_stride = (size_t)rig.J * 96;
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)pal_ring);
+    auto pal_dma = [&](uint32_t inst, uint32_t slot) {  // request one instance's palette rows into ring slot `slot`
+        const char* gbase = pal_g + (size_t)inst * pal_stride;
+        const uint32_t lds0 = ring_lds + slot * pal_slot_f * 4;
+        if (lane < npieces) SKINRT_GLDS_AT(joff0, gbase, lds0);
+        if (lane + 64 < npieces) {
+            const uint32_t lds1 = lds0 + 1024;
+            SKINRT_GLDS_AT(joff1, gbase, lds1);
+        }
+    };
+    auto morph_dma = [&](uint32_t hx) {  // request the first (up to) two active pairs of an instance into the slots
+        if (SKINRT_ABLATE & 2) return;
+        const uint32_t ns = min(hx & 0xffu, kMorphSlots);
+        const uint32_t lane_bytes = lane * 16;
+        for (uint32_t a = 0; a < ns; ++a) {
+            const MorphPair mp = pairs_s[(hx >> (16 + 8 * a)) & 0xffu];
+            const uint32_t doff = __builtin_amdgcn_readfirstlane(mp.data_off);
+            const bool dense = __builtin_amdgcn_readfirstlane((uint32_t)mp.dense) != 0;
+            const uint32_t n4 = dense ? kMorphWaveFloats / 4 : (__builtin_amdgcn_readfirstlane(mp.floats) + 3) / 4;
+            const float* gbase = rig.mblock + (doff + (dense ? wave * kMorphWaveFloats : 0u));
+            const uint32_t lds_base = __builtin_amdgcn_readfirstlane(
+                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)(my_slots + a * kMorphWaveFloats));
+            if (lane < n4) SKINRT_GLDS(0);
+            if (lane + 64 < n4) SKINRT_GLDS(1024);
+            if (lane + 128 < n4) SKINRT_GLDS(2048);
+        }
+    };
+    __syncthreads();  // headers visible
+
+    // ---------------- per-wave pipeline ----------------
+    for (uint32_t q = 0; q < min(L, nin); ++q) pal_dma(__builtin_amdgcn_readfirstlane(hdr_s[q].y), q % R);
+    uint32_t hx, hi, hz, hw;
+    {
+        const uint4 h0 = hdr_s[0];
+        hx = __builtin_amdgcn_readfirstlane(h0.x);
+        hi = __builtin_amdgcn_readfirstlane(h0.y);
+        hz = __builtin_amdgcn_readfirstlane(h0.z);
+        hw = __builtin_amdgcn_readfirstlane(h0.w);
+    }
+    if ((hx & 0xffu) && exact_mask) morph_dma(hx);
+    wait_vmcnt<0>();
+    bool dma_pending = true;  // "this instance's morph pairs were requested": true for instance 0 (just waited for everything)
+    uint32_t inst_ahead = nin > L ? __builtin_amdgcn_readfirstlane(hdr_s[L].y) : 0u;  // instance at pos + L
+    for (uint32_t pos = 0; pos < nin; ++pos) {
+        const uint32_t i = hi;
+        const uint32_t na = (SKINRT_ABLATE & 1) ? 0u : (hx & 0xffu);
+        const bool reload = ((hx >> 8) & 1u) != 0;
+        const bool fast = ((hx >> 9) & 1u) != 0;
+        const float mw1 = __uint_as_float(hz), mw2 = __uint_as_float(hw);
+        const size_t obase = (size_t)i * rig.V * 3;
+        // (1) wait: this instance's palette was requested L instances ago and every instance since
+        // issued at least spi stores; its morph pairs (if they had to be reloaded) were requested
+        // before the previous instance's last spi - 1 stores.  First instance: everything has landed.
+        if (pos) {
+            if ((hx & 0xffu) && reload && exact_mask && dma_pending) wait_vmcnt_dyn(spi ? spi - 1 : 0);
+            else wait_vmcnt_dyn(spi * L);
+        }
+        // (2) request the palette of instance pos + L, and fetch the instance id after that one
+        uint32_t ahead_next = 0;
+        if (pos + L < nin) {
+            pal_dma(inst_ahead, (pos + L) % R);
+            if (pos + L + 1 < nin) ahead_next = hdr_s[pos + L + 1].y;
+        }
+        uint4 hdr_next = make_uint4(0, 0, 0, 0);
+        if (pos + 1 < nin) hdr_next = hdr_s[pos + 1];
+        // (3) morph (a13): p = p0 + sum_m w_m * delta_m, targets ascending
+        float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
+        if (na) {
+            if (fast) {
+                morph_pair<EXACT>(my_slots, true, tid, mw1, p, n, t);
+                if (na >= 2) morph_pair<EXACT>(my_slots + kMorphWaveFloats, true, tid, mw2, p, n, t);
+            } else {
+                // general case (3+ active pairs, compacted pairs, more than 32 pairs in the tile):
+                // weights and the pairs beyond the slots come by plain loads, which wait for every
+                // store in flight — rare
+                const float* mwg = cr.mw + (size_t)i * M;
+                uint32_t a = 0;
+                for (uint32_t q = 0; q < np; ++q) {
+                    const MorphPair mp = pairs_s[q];
+                    const float mw = mwg[mp.target];
+                    if (mw == 0.0f) continue;  // wave-uniform
+                    const bool dense = mp.dense != 0;
+                    if (a < kMorphSlots && exact_mask) morph_pair<EXACT>(my_slots + a * kMorphWaveFloats, dense, tid, mw, p, n, t);
+                    else morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
+                    ++a;
+                }
+            }
+        }
+        // (4) position
+        float op[3];
+        {
+            float S[12];
+            blend_position<EXACT, K>(LdsPal{reinterpret_cast<const f4*>(pal_ring + (pos % R) * pal_slot_f)}, w, li, S);
+            apply_position<EXACT>(S, p, op);
+        }
+        if (valid) store3(out.pos + obase, olb, op);
+        // (5) request the next instance's morph pairs: every slot read of this instance has retired
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        hx = __builtin_amdgcn_readfirstlane(hdr_next.x);
+        hi = __builtin_amdgcn_readfirstlane(hdr_next.y);
+        hz = __builtin_amdgcn_readfirstlane(hdr_next.z);
+        hw = __builtin_amdgcn_readfirstlane(hdr_next.w);
+        inst_ahead = __builtin_amdgcn_readfirstlane(ahead_next);
+        dma_pending = false;
+        if ((hx & 0xffu) && ((hx >> 8) & 1u) && exact_mask) { morph_dma(hx); dma_pending = true; }
+        __builtin_amdgcn_sched_barrier(0);  // the stores below stay younger than the requests above
+        // (6) normal / tangent
+        float on[3], ot[3];
+        {
+            float Nm[9];
+            blend_normal<EXACT, K>(LdsPal{reinterpret_cast<const f4*>(pal_ring + (pos % R) * pal_slot_f)}, w, li, Nm);
+            apply_normal<EXACT>(Nm, n, t, normalize, on, ot);
+        }
+        if (valid) {
+            store3(out.nrm + obase, olb, on);
+            store3(out.tan + obase, olb, ot);
+        }
+        // (7) bounds of this wave's 64 vertices (lanes past the mesh end repeat a real vertex)
+        if (plan.aabb) {
+            float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
+            wave_minmax6(a0, a1, a2, b0, b1, b2);
+            uint32_t lid;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
+            if (lid == 63) {
+                float* dst = cr.aabb_part + (((size_t)i * rig.T + tile) * 4 + wave) * 6;
+                const float lo[3] = {a0, a1, a2}, hi3[3] = {b0, b1, b2};
+                store3(dst, 0u, lo);
+                store3(dst + 3, 0u, hi3);
+            }
+        }
+    }
+}
+
 // a14: bounds of one instance = min/max over its tiles' partial bounds (order-independent, exact).
 // One 192-thread block per instance: an instance's partials are 6*T contiguous floats, thread t owns
 // component t % 6 and strides by 192 (a multiple of 6), so every load is coalesced.
@@ -642,8 +967,8 @@ constexpr uint32_t kAabbThreads = 192;
 __global__ __launch_bounds__(kAabbThreads) void k_aabb_reduce(const RigDev rig, const CrowdDev cr) {
     __shared__ float part[kAabbThreads];
     const uint32_t i = blockIdx.x, t = threadIdx.x, c = t % 6;
-    const float* src = cr.aabb_part + (size_t)i * rig.T * 6;
-    const uint32_t n = rig.T * 6;
+    const float* src = cr.aabb_part + (size_t)i * rig.T * 24;  // [T][4 waves][6]
+    const uint32_t n = rig.T * 24;
     float r = c < 3 ? __builtin_inff() : -__builtin_inff();
     for (uint32_t e = t; e < n; e += kAabbThreads) r = c < 3 ? fminf(r, src[e]) : fmaxf(r, src[e]);
     part[t] = r;
@@ -683,10 +1008,26 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         (uint64_t)plan.tiles_per_chunk * plan.tile_chunks < rig.T ||
         (uint64_t)plan.ranges_per_chunk * (8 / plan.tile_chunks) < plan.ranges)
         return hipErrorInvalidValue;
+    if (plan.v2 && (plan.range2 == 0 || plan.range2 > kSkin2Range || (uint64_t)plan.ranges2 * plan.range2 < cr.I ||
+                    plan.lds_bytes2 > 64 * 1024 || rig.K > 2 || plan.jt2_shift > 5 ||
+                    (uint64_t)plan.ranges_per_chunk2 * (8 / plan.tile_chunks) < plan.ranges2))
+        return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
-    if (plan.lds_tiles)
+    // tiles of kind 2 (short joint lists): the self-staging kernel unless it is switched off
+    if (plan.v2 && (plan.kinds & 4u)) {
+        const dim3 grid(8u * plan.tiles_per_chunk * plan.ranges_per_chunk2), block(kSkin2Threads);
+        if (rig.K == 1) {
+            if (plan.exact) hipLaunchKernelGGL((k_skin2<true, 1>), grid, block, plan.lds_bytes2, s, rig, cr, plan);
+            else hipLaunchKernelGGL((k_skin2<false, 1>), grid, block, plan.lds_bytes2, s, rig, cr, plan);
+        } else {
+            if (plan.exact) hipLaunchKernelGGL((k_skin2<true, 2>), grid, block, plan.lds_bytes2, s, rig, cr, plan);
+            else hipLaunchKernelGGL((k_skin2<false, 2>), grid, block, plan.lds_bytes2, s, rig, cr, plan);
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && ((plan.kinds & 2u) || (!plan.v2 && (plan.kinds & 4u))))
         e = plan.exact ? launch_skin_k<true, true>(rig, cr, plan, s) : launch_skin_k<false, true>(rig, cr, plan, s);
-    if (e == hipSuccess && plan.lds_tiles < rig.T)
+    if (e == hipSuccess && (plan.kinds & 1u))
         e = plan.exact ? launch_skin_k<true, false>(rig, cr, plan, s) : launch_skin_k<false, false>(rig, cr, plan, s);
     return e;
 }

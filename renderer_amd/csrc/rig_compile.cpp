@@ -243,7 +243,10 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
         std::sort(list.begin(), list.end());
         for (uint32_t i = 0; i < list.size(); ++i) local_of[list[i]] = i;
         const bool lds = list.size() <= kTileJointCap;
-        r.tile_lds[t] = lds ? 1 : 0;
+        // 2: short list (its 16-byte palette pieces fit two LDS-DMA instructions: the self-staging
+        // kernel), 1: fits the loader-wave kernel's LDS staging, 0: gathers from L2
+        r.tile_lds[t] = lds ? (list.size() * 6 <= 128 ? 2 : 1) : 0;
+        r.tile_kind_count[r.tile_lds[t]] += 1;
         r.lds_tiles += lds ? 1 : 0;
         r.max_tile_joints_any = std::max<uint32_t>(r.max_tile_joints_any, (uint32_t)list.size());
         if (lds) r.max_tile_joints = std::max<uint32_t>(r.max_tile_joints, (uint32_t)list.size());

@@ -35,6 +35,9 @@ struct MorphPair {
     uint16_t dense;
     uint32_t reserved;
 };
+constexpr uint32_t kSkin2Range = 128;         // instances per block of the self-staging skinning kernel
+constexpr uint32_t kSkin2PalLook = 2;         // its palette LDS-DMA runs this many instances ahead
+constexpr uint32_t kSkin2PalRing = kSkin2PalLook + 1;
 constexpr uint32_t kMorphWaveFloats = 576;    // one wave's share of a dense pair = one LDS slot
 constexpr uint32_t kMorphDenseMin = 57;       // touched vertices from which a pair is stored dense
                                               // (a sparse region, 64 + 56*9 floats, still fits a slot)
@@ -67,7 +70,8 @@ struct CompiledRig {
     std::vector<uint16_t> lidx;         // [T][4K][256] tile-local joint index (LDS tiles) or global joint id
     std::vector<uint32_t> tile_joint_start;  // [T+1]
     std::vector<uint32_t> tile_joints;       // concatenated tile joint lists (global ids, ascending)
-    std::vector<uint8_t> tile_lds;           // [T] 1 = joint list fits kTileJointCap
+    std::vector<uint8_t> tile_lds;           // [T] 0 = joint list exceeds kTileJointCap, 1 = fits, 2 = at most 21 joints
+    uint32_t tile_kind_count[3] = {0, 0, 0}; // tiles of each kind
     uint32_t max_tile_joints = 0;            // over LDS tiles
     uint32_t max_tile_joints_any = 0;
     uint32_t lds_tiles = 0;

@@ -40,13 +40,14 @@ def _check_all(got, ref, exact_pose=True, exact_skin=False, tag=""):
         assert_close(got["aabb"], ref["aabb"], tag + "aabb")
 
 
+@pytest.mark.parametrize("skin_path", [0, 1])   # 0: self-staging kernel where it applies, 1: loader-wave kernel only
 @pytest.mark.parametrize("pose_path", [1, 2])
 @pytest.mark.parametrize("exact", [1, 0])
-def test_tiny_rig_all_features(oracle32, pose_path, exact):
+def test_tiny_rig_all_features(oracle32, pose_path, exact, skin_path):
     spec = synth.tiny_spec(matrix_nodes=1)
     rig = synth.make_rig(spec)
     crowd = synth.make_crowd(spec, rig, instances=7, with_root=True)
-    got = run_gpu(rig, crowd, pose_path=pose_path, exact_arithmetic=exact)
+    got = run_gpu(rig, crowd, pose_path=pose_path, exact_arithmetic=exact, skin_path=skin_path)
     ref = run_oracle(oracle32, rig, crowd)
     _check_all(got, ref, exact_pose=True, exact_skin=bool(exact))
 
@@ -73,13 +74,14 @@ def test_normalized_outputs(oracle32):
     assert_close(np.linalg.norm(got["normal"], axis=2), np.ones((4, rig.vertex_count)), "unit normals", rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("name,inst", [("c1", 1), ("c2", 64), ("c3", 6)])
+@pytest.mark.parametrize("skin_path", [0, 1])
+@pytest.mark.parametrize("name,inst", [("c1", 1), ("c2", 64), ("c3", 6), ("c3", 300)])
 @pytest.mark.parametrize("exact", [1, 0])
-def test_config_shapes(oracle32, name, inst, exact):
+def test_config_shapes(oracle32, name, inst, exact, skin_path):
     spec = synth.CONFIGS[name]
     rig = synth.make_rig(spec)
     crowd = synth.make_crowd(spec, rig, instances=inst)
-    got = run_gpu(rig, crowd, exact_arithmetic=exact)
+    got = run_gpu(rig, crowd, exact_arithmetic=exact, skin_path=skin_path)
     ref = run_oracle(oracle32, rig, crowd)
     _check_all(got, ref, exact_skin=bool(exact), tag=name + ":")
 
