@@ -70,7 +70,7 @@ struct skinrt_crowd {
     skinrt_ctx* ctx = nullptr;
     skinrt_rig* rig = nullptr;
     uint32_t I = 0;
-    DevBuf tau, clip, mw, root, world, palette, keyidx, pos, nrm, tan, aabb_part, aabb;
+    DevBuf tau, clip, mw, root, world, palette, keyidx, pos, nrm, tan, aabb_part, aabb, fix;
     bool has_root = false;
     SkinPlan plan{};
     PosePath pose_path = kPoseWave;
@@ -84,6 +84,8 @@ struct skinrt_crowd {
         c.world = world.as<float>(); c.palette = palette.as<float>(); c.keyidx = keyidx.as<uint32_t>();
         c.pos = pos.as<float>(); c.nrm = nrm.as<float>(); c.tan = tan.as<float>();
         c.aabb_part = aabb_part.as<float>(); c.aabb = aabb.as<float>();
+        c.fix = fix.p ? fix.as<uint32_t>() : nullptr;
+        c.fix_cap = fix.p ? (uint32_t)((fix.bytes - 16) / 8) : 0u;
         return c;
     }
 };
@@ -154,7 +156,7 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
     {
         p.jt2_shift = std::min<uint32_t>(p.jt_shift, 5);  // kind-2 tiles have at most 21 joints
         const uint32_t per_wave = kSkin2PalRing * (96u << p.jt2_shift) + (r.M ? kMorphSlots * kMorphWaveFloats * 4 : 0);
-        const uint32_t tables = kSkin2Range * (16 + 4 + 2) + p.max_pairs * 16 + 64;
+        const uint32_t tables = kSkin2Range * (16 + 4 + 2 + 24) + p.max_pairs * 16 + 64;  // headers, masks, order, bounds cells
         p.lds_bytes2 = tables + 4 * per_wave;
         if (p.lds_bytes2 > 64 * 1024) p.v2 = 0;
         uint64_t r2 = ((uint64_t)I * std::max<uint32_t>(1, r.T) + want_blocks - 1) / want_blocks;
@@ -289,7 +291,7 @@ int skinrt_destroy_crowd(skinrt_crowd* c) {
         (void)hipStreamSynchronize(c->ctx->stream);
     }
     for (DevBuf* b : {&c->tau, &c->clip, &c->mw, &c->root, &c->world, &c->palette, &c->keyidx, &c->pos, &c->nrm,
-                      &c->tan, &c->aabb_part, &c->aabb})
+                      &c->tan, &c->aabb_part, &c->aabb, &c->fix})
         b->release();
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -311,7 +313,8 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
         {&c->tau, I * 4}, {&c->clip, I * 4}, {&c->mw, I * h.M * 4}, {&c->root, I * 48},
         {&c->world, I * h.N * 48}, {&c->palette, I * h.J * 96}, {&c->keyidx, I * h.Cmax * 4},
         {&c->pos, I * h.V * 12}, {&c->nrm, I * h.V * 12}, {&c->tan, I * h.V * 12},
-        {&c->aabb_part, I * h.T * 4 * 24}, {&c->aabb, I * 24},  // bounds per (instance, tile, wave)
+        {&c->aabb_part, I * h.T * 24}, {&c->aabb, I * 24},      // bounds per (instance, tile)
+        {&c->fix, h.M ? 16 + I * h.T * 8 : 0},                   // work list of k_skin_fix
     };
     for (auto& it : plan) {
         hipError_t e = it.b->alloc(it.n);

@@ -265,6 +265,12 @@ __device__ __forceinline__ void store3(float* base, uint32_t byte_off, const flo
     asm volatile("global_store_dwordx3 %0, %1, %2" SKINRT_STORE_MOD "\n\ts_nop 1" : : "v"(byte_off), "v"(d), "s"(base) : "memory");
 }
 
+// the same without the streaming hint: small scattered records (bounds) that L2 should merge
+__device__ __forceinline__ void store3_cached(float* base, uint32_t byte_off, const float (&x)[3]) {
+    float3v d = {x[0], x[1], x[2]};
+    asm volatile("global_store_dwordx3 %0, %1, %2\n\ts_nop 1" : : "v"(byte_off), "v"(d), "s"(base) : "memory");
+}
+
 struct Outputs {
     float* pos;
     float* nrm;
@@ -501,10 +507,7 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
                 const float* src = ab_s + buf * ab_buf + (size_t)b * 16 * 6 + c;
                 float r = src[0];
                 for (int q = 1; q < 16; ++q) r = c < 3 ? fminf(r, src[q * 6]) : fmaxf(r, src[q * 6]);
-                // bounds are kept per (instance, tile, wave) for k_skin2; this kernel has one value per
-                // tile and writes it to all four entries (min / max are idempotent)
-                float* dst = cr.aabb_part + ((size_t)inst_at(pos0 + b) * rig.T + tile) * 24 + c;
-                dst[0] = r; dst[6] = r; dst[12] = r; dst[18] = r;
+                cr.aabb_part[((size_t)inst_at(pos0 + b) * rig.T + tile) * 6 + c] = r;
             }
         };
 
@@ -684,7 +687,17 @@ __device__ __forceinline__ void wait_vmcnt_dyn(uint32_t n) {
         case 2: wait_vmcnt<2>(); break;
         case 4: wait_vmcnt<4>(); break;
         case 6: wait_vmcnt<6>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
         case 10: wait_vmcnt<10>(); break;
+        case 12: wait_vmcnt<12>(); break;
+        case 15: wait_vmcnt<15>(); break;
+        case 16: wait_vmcnt<16>(); break;
+        case 18: wait_vmcnt<18>(); break;
+        case 20: wait_vmcnt<20>(); break;
+        case 24: wait_vmcnt<24>(); break;
+        case 30: wait_vmcnt<30>(); break;
+        case 40: wait_vmcnt<40>(); break;
         default: wait_vmcnt<0>(); break;
     }
 }
@@ -732,7 +745,8 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     uint32_t* mask_s = reinterpret_cast<uint32_t*>(hdr_s + kSkin2Range);        // [128] active-pair mask per instance-in-range
     uint16_t* perm_s = reinterpret_cast<uint16_t*>(mask_s + kSkin2Range);       // [128] processing order
     MorphPair* pairs_s = reinterpret_cast<MorphPair*>(perm_s + kSkin2Range + 32);  // [max_pairs] (+32: keeps 16-byte alignment)
-    float* wave_s = reinterpret_cast<float*>(pairs_s + plan.max_pairs);
+    float* bb_s = reinterpret_cast<float*>(pairs_s + plan.max_pairs);              // [128][6] bounds per processing position
+    float* wave_s = bb_s + kSkin2Range * 6;
     const uint32_t pal_slot_f = JTP * 24;                                       // floats per palette slot
     const uint32_t per_wave_f = R * pal_slot_f + (M ? kMorphSlots * kMorphWaveFloats : 0u);
     float* pal_ring = wave_s + (size_t)wave * per_wave_f;                       // [R][JTP][6] f4
@@ -746,19 +760,46 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
 
     // ---------------- block prologue (all 256 threads; no store has been issued yet) ----------------
     for (uint32_t c = tid; c < np; c += kSkin2Threads) pairs_s[c] = rig.pairs[pbeg + c];
+    if (plan.aabb)
+        for (uint32_t c = tid; c < kSkin2Range * 6; c += kSkin2Threads) bb_s[c] = (c % 6 < 3) ? __builtin_inff() : -__builtin_inff();
     __syncthreads();
-    // active-pair mask of instance-in-range `tid` (bit min(q, 31) = pair q has a non-zero weight)
-    uint32_t my_mask = 0xffffffffu;  // padding sorts last
-    if (tid < kSkin2Range) {
+    // active-pair mask of instance-in-range `tid` (bit min(q, 31) = pair q has a non-zero weight).
+    // This kernel morphs from its two LDS slots only: an instance with 1 or 2 active pairs, both
+    // dense.  Every other non-idle (tile, instance) — 3+ active pairs, a compacted pair, a tile with
+    // more than 32 pairs — goes on the work list of k_skin_fix and is left out of this block's order.
+    uint32_t* cnt_s = reinterpret_cast<uint32_t*>(wave_s);      // [6], overlaid on the (still unused) wave area
+    uint32_t my_mask = 0xffffffffu;  // padding and handed-over instances sort last
+    {
+        bool slow = false;
         if (tid < nin) {
             my_mask = 0;
+            uint32_t sparse = 0;
             const float* mwg = cr.mw + (size_t)(i0 + tid) * M;
-            for (uint32_t q = 0; q < np; ++q)
-                if (mwg[pairs_s[q].target] != 0.0f) my_mask |= 1u << min(q, 31u);
+            for (uint32_t q = 0; q < np; ++q) {
+                const MorphPair mp = pairs_s[q];
+                if (mwg[mp.target] != 0.0f) my_mask |= 1u << min(q, 31u);
+                if (!mp.dense) sparse |= 1u << min(q, 31u);
+            }
+            slow = my_mask != 0 && (!exact_mask || __popc(my_mask) > 2 || (my_mask & sparse) != 0);
+            if (SKINRT_ABLATE & 4) { slow = false; my_mask = 0; }
         }
-        mask_s[tid] = my_mask;
+        const uint64_t bslow = __ballot(slow);
+        if (bslow) {  // wave-uniform
+            const uint32_t n = (uint32_t)__popcll(bslow);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(cr.fix, n);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (slow) {
+                const uint32_t e = base + (uint32_t)__popcll(bslow & ((1ull << lane) - 1ull));
+                if (e < cr.fix_cap) *reinterpret_cast<uint2*>(cr.fix + 4 + 2 * (size_t)e) = make_uint2(tile, i0 + tid);
+                my_mask = 0xffffffffu;
+            }
+        }
+        if (lane == 0 && wave < 2) cnt_s[4 + wave] = (uint32_t)__popcll(bslow);
+        if (tid < kSkin2Range) mask_s[tid] = my_mask;
     }
     __syncthreads();
+    const uint32_t nproc = nin - cnt_s[4] - cnt_s[5];  // instances this block processes itself
     // processing order: equal masks become neighbours (rank sort on distinct (mask, index) keys)
     if (tid < kSkin2Range) {
         uint32_t rank = 0;
@@ -772,32 +813,68 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         perm_s[rank] = (uint16_t)tid;
     }
     __syncthreads();
-    // header of the instance at position `tid`:
-    //   x = active pairs (0xff: unknown, more than 32 pairs in the tile) | reload << 8 | fast << 9 |
-    //       first active pair << 16 | second << 24;  y = instance;  z, w = weights of those two pairs
-    // reload: the slots hold another set (its predecessor's mask differs); fast: 1 or 2 active
-    // pairs, both dense -> this header and the slots are all the instance needs.
-    if (tid < nin) {
+    // Run structure of the sorted order.  Instances with no active pair (mask 0, sorted first) never
+    // read the morph slots, so they are dealt out as SPACERS between runs of equal masks: the pairs
+    // of the run after a spacer are requested at the spacer's first instance, at least L instances
+    // before they are read, and the ordinary palette wait then covers them — no store has to drain.
+    // Runs that get no spacer (too few idle instances) request their pairs one instance ahead and
+    // wait for all but that instance's last stores ("near" reload).
+    uint16_t* start_s = reinterpret_cast<uint16_t*>(cnt_s + 8); // [runs] sorted position where run j starts
+    const bool in_range = tid < nproc;
+    const uint32_t sm = in_range ? mask_s[perm_s[tid]] : 0xffffffffu;
+    const uint32_t sprev = (in_range && tid) ? mask_s[perm_s[tid - 1]] : 0u;
+    const bool nz = in_range && sm != 0;
+    const bool start = nz && (tid == 0 || sm != sprev);
+    const uint64_t bstart = __ballot(start), bzero = __ballot(in_range && !nz);
+    if (wave < 2 && lane == 0) { cnt_s[wave * 2] = (uint32_t)__popcll(bstart); cnt_s[wave * 2 + 1] = (uint32_t)__popcll(bzero); }
+    __syncthreads();
+    const uint32_t runs = cnt_s[0] + cnt_s[2];
+    const uint32_t zeros = cnt_s[1] + cnt_s[3];
+    const uint32_t run = (wave == 1 ? cnt_s[0] : 0u) + (uint32_t)__popcll(bstart & ((2ull << lane) - 1ull)) - 1u;  // of a non-zero element
+    if (start && tid < kSkin2Range) start_s[run] = (uint16_t)tid;
+    uint32_t nsp = 0, sp = 0;  // spacers, instances per spacer
+    if (runs > 1) {
+        nsp = min(runs - 1, zeros / L);
+        if (nsp) sp = zeros / nsp;
+    }
+    const uint32_t z0 = zeros - nsp * sp;  // idle instances left over: processed first
+    __syncthreads();
+    // header of one instance, written at its processing position:
+    //   x = active pairs (0, 1 or 2) | near << 8 | prefetch << 10 | pairs to prefetch << 11 |
+    //       first pair << 16 | second << 24;   y = instance;   z, w = weights of those two pairs
+    // near: its pairs are requested during the previous instance; prefetch (idle instances only):
+    // request the named pairs, which belong to the run after this spacer.
+    if (in_range) {
         const uint32_t k = perm_s[tid];
-        const uint32_t m = mask_s[k];
-        const uint32_t prev = tid ? mask_s[perm_s[tid - 1]] : ~m;
         const uint32_t inst = i0 + k;
-        uint32_t na = exact_mask ? (uint32_t)__popc(m) : (m ? 0xffu : 0u);
-        if (SKINRT_ABLATE & 4) na = 0;
-        uint32_t q1 = 0, q2 = 0, fast = 0;
+        uint32_t m = sm, fpos, near = 0, pf = 0;
+        if (nz) {
+            fpos = z0 + (tid - zeros) + min(run, nsp) * sp;
+            near = (start && run > nsp) ? 1u : 0u;
+        } else if (tid < z0) {
+            fpos = tid;
+        } else {
+            const uint32_t idx = tid - z0, sj = idx / sp, within = idx - sj * sp;
+            const uint32_t nxt = start_s[sj + 1];
+            fpos = z0 + (nxt - zeros) + sj * sp + within;
+            if (within == 0) { pf = 1; m = mask_s[perm_s[nxt]]; }  // describe the next run's pairs
+        }
+        const uint32_t na = (uint32_t)__popc(m);  // <= 2
+        uint32_t q1 = 0, q2 = 0;
         float w1 = 0.0f, w2 = 0.0f;
-        if (exact_mask && na >= 1) {
+        if (na >= 1) {
             q1 = (uint32_t)__ffs((int)m) - 1;
             const uint32_t m2 = m & (m - 1);
             q2 = m2 ? (uint32_t)__ffs((int)m2) - 1 : q1;
             const MorphPair p1 = pairs_s[q1], p2 = pairs_s[q2];
-            w1 = cr.mw[(size_t)inst * M + p1.target];
-            w2 = cr.mw[(size_t)inst * M + p2.target];
-            fast = (kMorphSlots >= 2 && na <= 2 && p1.dense && (na == 1 || p2.dense)) ? 1u : 0u;
+            if (!pf) {
+                w1 = cr.mw[(size_t)inst * M + p1.target];
+                w2 = cr.mw[(size_t)inst * M + p2.target];
+            }
         }
-        const uint32_t reload = (m != prev || !exact_mask) ? 1u : 0u;
-        hdr_s[tid] = make_uint4(na | (reload << 8) | (fast << 9) | (q1 << 16) | (q2 << 24), inst,
-                                __float_as_uint(w1), __float_as_uint(w2));
+        const uint32_t x = pf ? ((1u << 10) | (na << 11) | (q1 << 16) | (q2 << 24))
+                              : (na | (near << 8) | (q1 << 16) | (q2 << 24));
+        hdr_s[fpos] = make_uint4(x, inst, __float_as_uint(w1), __float_as_uint(w2));
     }
     // this thread's vertex
     const uint32_t v = tile * TV + tid;
@@ -823,11 +900,12 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     const bool normalize = plan.normalize != 0;
     const uint32_t wave_valid = __builtin_amdgcn_readfirstlane(__ballot(valid) != 0ull ? 1u : 0u);
     // stores this wave issues per instance: position / normal / tangent (none if the wave holds no
-    // real vertex), plus two for its bounds
-    const uint32_t spi = (wave_valid ? 3u : 0u) + (plan.aabb ? 2u : 0u);
+    // real vertex)
+    const uint32_t spi = wave_valid ? 3u : 0u;
     const char* pal_g = reinterpret_cast<const char*>(cr.palette);
     const size_t pal_stride = (size_t)rig.J * 96;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)pal_ring);
+    const uint32_t bb_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)bb_s);
     auto pal_dma = [&](uint32_t inst, uint32_t slot) {  // request one instance's palette rows into ring slot `slot`
         const char* gbase = pal_g + (size_t)inst * pal_stride;
         const uint32_t lds0 = ring_lds + slot * pal_slot_f * 4;
@@ -857,7 +935,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     __syncthreads();  // headers visible
 
     // ---------------- per-wave pipeline ----------------
-    for (uint32_t q = 0; q < min(L, nin); ++q) pal_dma(__builtin_amdgcn_readfirstlane(hdr_s[q].y), q % R);
+    for (uint32_t q = 0; q < min(L, nproc); ++q) pal_dma(__builtin_amdgcn_readfirstlane(hdr_s[q].y), q % R);
     uint32_t hx, hi, hz, hw;
     {
         const uint4 h0 = hdr_s[0];
@@ -866,54 +944,38 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         hz = __builtin_amdgcn_readfirstlane(h0.z);
         hw = __builtin_amdgcn_readfirstlane(h0.w);
     }
-    if ((hx & 0xffu) && exact_mask) morph_dma(hx);
+    // the first run's pairs (wherever it starts: the slots are idle until then)
+    if (runs) morph_dma(z0 ? __builtin_amdgcn_readfirstlane(hdr_s[z0].x) : hx);
     wait_vmcnt<0>();
     bool dma_pending = true;  // "this instance's morph pairs were requested": true for instance 0 (just waited for everything)
-    uint32_t inst_ahead = nin > L ? __builtin_amdgcn_readfirstlane(hdr_s[L].y) : 0u;  // instance at pos + L
-    for (uint32_t pos = 0; pos < nin; ++pos) {
+    uint32_t inst_ahead = nproc > L ? __builtin_amdgcn_readfirstlane(hdr_s[L].y) : 0u;  // instance at pos + L
+    for (uint32_t pos = 0; pos < nproc; ++pos) {
         const uint32_t i = hi;
         const uint32_t na = (SKINRT_ABLATE & 1) ? 0u : (hx & 0xffu);
         const bool reload = ((hx >> 8) & 1u) != 0;
-        const bool fast = ((hx >> 9) & 1u) != 0;
         const float mw1 = __uint_as_float(hz), mw2 = __uint_as_float(hw);
         const size_t obase = (size_t)i * rig.V * 3;
         // (1) wait: this instance's palette was requested L instances ago and every instance since
         // issued at least spi stores; its morph pairs (if they had to be reloaded) were requested
         // before the previous instance's last spi - 1 stores.  First instance: everything has landed.
         if (pos) {
-            if ((hx & 0xffu) && reload && exact_mask && dma_pending) wait_vmcnt_dyn(spi ? spi - 1 : 0);
+            if (reload && dma_pending) wait_vmcnt_dyn(spi ? spi - 1 : 0);
             else wait_vmcnt_dyn(spi * L);
         }
         // (2) request the palette of instance pos + L, and fetch the instance id after that one
         uint32_t ahead_next = 0;
-        if (pos + L < nin) {
+        if (pos + L < nproc) {
             pal_dma(inst_ahead, (pos + L) % R);
-            if (pos + L + 1 < nin) ahead_next = hdr_s[pos + L + 1].y;
+            if (pos + L + 1 < nproc) ahead_next = hdr_s[pos + L + 1].y;
         }
+        if ((hx >> 10) & 1u) morph_dma((hx & 0xffff0000u) | ((hx >> 11) & 3u));  // spacer: the next run's pairs
         uint4 hdr_next = make_uint4(0, 0, 0, 0);
-        if (pos + 1 < nin) hdr_next = hdr_s[pos + 1];
+        if (pos + 1 < nproc) hdr_next = hdr_s[pos + 1];
         // (3) morph (a13): p = p0 + sum_m w_m * delta_m, targets ascending
         float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
         if (na) {
-            if (fast) {
-                morph_pair<EXACT>(my_slots, true, tid, mw1, p, n, t);
-                if (na >= 2) morph_pair<EXACT>(my_slots + kMorphWaveFloats, true, tid, mw2, p, n, t);
-            } else {
-                // general case (3+ active pairs, compacted pairs, more than 32 pairs in the tile):
-                // weights and the pairs beyond the slots come by plain loads, which wait for every
-                // store in flight — rare
-                const float* mwg = cr.mw + (size_t)i * M;
-                uint32_t a = 0;
-                for (uint32_t q = 0; q < np; ++q) {
-                    const MorphPair mp = pairs_s[q];
-                    const float mw = mwg[mp.target];
-                    if (mw == 0.0f) continue;  // wave-uniform
-                    const bool dense = mp.dense != 0;
-                    if (a < kMorphSlots && exact_mask) morph_pair<EXACT>(my_slots + a * kMorphWaveFloats, dense, tid, mw, p, n, t);
-                    else morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
-                    ++a;
-                }
-            }
+            morph_pair<EXACT>(my_slots, true, tid, mw1, p, n, t);
+            if (na >= 2) morph_pair<EXACT>(my_slots + kMorphWaveFloats, true, tid, mw2, p, n, t);
         }
         // (4) position
         float op[3];
@@ -931,7 +993,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         hw = __builtin_amdgcn_readfirstlane(hdr_next.w);
         inst_ahead = __builtin_amdgcn_readfirstlane(ahead_next);
         dma_pending = false;
-        if ((hx & 0xffu) && ((hx >> 8) & 1u) && exact_mask) { morph_dma(hx); dma_pending = true; }
+        if ((hx >> 8) & 1u) { morph_dma(hx); dma_pending = true; }
         __builtin_amdgcn_sched_barrier(0);  // the stores below stay younger than the requests above
         // (6) normal / tangent
         float on[3], ot[3];
@@ -944,17 +1006,114 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
             store3(out.nrm + obase, olb, on);
             store3(out.tan + obase, olb, ot);
         }
-        // (7) bounds of this wave's 64 vertices (lanes past the mesh end repeat a real vertex)
+        // (7) bounds of this wave's 64 vertices (lanes past the mesh end repeat a real vertex), folded
+        // into the block's cell for this position with LDS atomics: nothing is returned, so nothing
+        // waits.  Per-wave records in HBM (two 12-byte stores per wave and instance) cost 0.8-1.2 ms
+        // of the C3 frame as scattered partial-line writes.
         if (plan.aabb) {
             float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
             wave_minmax6(a0, a1, a2, b0, b1, b2);
             uint32_t lid;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
             if (lid == 63) {
-                float* dst = cr.aabb_part + (((size_t)i * rig.T + tile) * 4 + wave) * 6;
-                const float lo[3] = {a0, a1, a2}, hi3[3] = {b0, b1, b2};
-                store3(dst, 0u, lo);
-                store3(dst + 3, 0u, hi3);
+                // asm: left to the compiler, an LDS atomic on a wave-uniform address is wrapped in a
+                // lane loop that pre-reduces the (here: single) active lane
+                const uint32_t cell = bb_lds + pos * 24;
+                asm volatile("ds_min_f32 %0, %1\n\tds_min_f32 %0, %2 offset:4\n\tds_min_f32 %0, %3 offset:8\n\t"
+                             "ds_max_f32 %0, %4 offset:12\n\tds_max_f32 %0, %5 offset:16\n\tds_max_f32 %0, %6 offset:20"
+                             : : "v"(cell), "v"(a0), "v"(a1), "v"(a2), "v"(b0), "v"(b1), "v"(b2) : "memory");
+            }
+        }
+    }
+    // ---------------- block epilogue: one bounds record per (instance, tile) ----------------
+    if (plan.aabb) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm atomics above
+        __syncthreads();
+        if (tid < nproc) {
+            const float* cell = bb_s + tid * 6;
+            float* dst = cr.aabb_part + ((size_t)hdr_s[tid].y * rig.T + tile) * 6;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) dst[c] = cell[c];
+        }
+    }
+}
+
+// k_skin_fix — the (tile, instance) pairs k_skin2 left out: instances with three or more active
+// morph pairs in the tile, with a compacted pair, or in a tile with more than 32 pairs.  A block
+// takes kFixChunk consecutive work-list entries (k_skin2 blocks append theirs together, so the
+// tile — and with it the block's vertex data — rarely changes inside a chunk).  Per entry the
+// palette rows of the tile's joints are staged in LDS (at most 126 16-byte pieces), the active
+// pairs' deltas come by plain loads (L2-resident), and resident blocks cover each other's latency.
+// Same arithmetic, in the same order, as the staged kernels (a13: targets ascending).
+constexpr uint32_t kFixChunk = 8;
+template <bool EXACT, int K>
+__global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
+    constexpr uint32_t TV = kTileVerts;
+    constexpr int W = 4 * K;
+    __shared__ f4 pal_s[2][128];
+    __shared__ float part[4][6];
+    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t count = min(cr.fix[0], cr.fix_cap);
+    const Outputs out{cr.pos, cr.nrm, cr.tan};
+    const bool normalize = plan.normalize != 0;
+    const uint32_t M = rig.M;
+    const f4* pal_g = reinterpret_cast<const f4*>(cr.palette);
+    for (uint32_t e0 = blockIdx.x * kFixChunk; e0 < count; e0 += gridDim.x * kFixChunk) {
+        const uint32_t e1 = min(count, e0 + kFixChunk);
+        uint32_t cur_tile = 0xffffffffu, jstart = 0, npieces = 0, pbeg = 0, pend = 0, joff = 0;
+        bool valid = false;
+        float p0[3], n0[3], t0[3], w[W];
+        uint32_t li[W];
+        for (uint32_t e = e0; e < e1; ++e) {
+            const uint2 ent = *reinterpret_cast<const uint2*>(cr.fix + 4 + 2 * (size_t)e);
+            const uint32_t tile = __builtin_amdgcn_readfirstlane(ent.x), inst = __builtin_amdgcn_readfirstlane(ent.y);
+            if (tile != cur_tile) {  // block-uniform
+                cur_tile = tile;
+                valid = tile * TV + tid < rig.V;
+                const float* b = rig.base + (size_t)tile * 9 * TV + tid;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) { p0[x] = b[x * TV]; n0[x] = b[(3 + x) * TV]; t0[x] = b[(6 + x) * TV]; }
+                const float* wt = rig.wts + (size_t)tile * W * TV + tid;
+                const uint16_t* lp = rig.lidx + (size_t)tile * W * TV + tid;
+#pragma unroll
+                for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
+                jstart = rig.tile_joint_start[tile];
+                npieces = (rig.tile_joint_start[tile + 1] - jstart) * 6;  // <= 126 for k_skin2's tiles
+                joff = tid < npieces ? rig.tile_joints[jstart + tid / 6] * 6 + tid % 6 : 0u;
+                pbeg = rig.tile_pair_start[tile];
+                pend = rig.tile_pair_start[tile + 1];
+            }
+            // stage this instance's palette rows; the buffers alternate, so the one barrier below
+            // also separates the previous entry's reads of this buffer from these writes
+            f4* ps = pal_s[(e - e0) & 1];
+            if (tid < npieces) ps[tid] = pal_g[(size_t)inst * rig.J * 6 + joff];
+            float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
+            const float* mwg = cr.mw + (size_t)inst * M;
+            for (uint32_t q = pbeg; q < pend; ++q) {
+                const MorphPair mp = rig.pairs[q];
+                const float mw = mwg[mp.target];
+                if (mw == 0.0f) continue;  // wave-uniform; a zero weight adds exactly 0
+                const bool dense = mp.dense != 0;
+                morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
+            }
+            __syncthreads();
+            float op[3];
+            skin_store<EXACT, K>(LdsPal{ps}, w, li, p, n, t, normalize, valid, out, (size_t)inst * rig.V * 3,
+                                 (tile * TV + tid) * 12, op);
+            if (plan.aabb) {
+                float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
+                wave_minmax6(a0, a1, a2, b0, b1, b2);
+                if ((tid & 63) == 63) {
+                    float* dst = part[wave];
+                    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = b0; dst[4] = b1; dst[5] = b2;
+                }
+                __syncthreads();
+                if (tid < 6) {
+                    float r = part[0][tid];
+                    for (int q = 1; q < 4; ++q) r = tid < 3 ? fminf(r, part[q][tid]) : fmaxf(r, part[q][tid]);
+                    cr.aabb_part[((size_t)inst * rig.T + tile) * 6 + tid] = r;
+                }
+                // part[] is next written after the next entry's first barrier
             }
         }
     }
@@ -967,8 +1126,8 @@ constexpr uint32_t kAabbThreads = 192;
 __global__ __launch_bounds__(kAabbThreads) void k_aabb_reduce(const RigDev rig, const CrowdDev cr) {
     __shared__ float part[kAabbThreads];
     const uint32_t i = blockIdx.x, t = threadIdx.x, c = t % 6;
-    const float* src = cr.aabb_part + (size_t)i * rig.T * 24;  // [T][4 waves][6]
-    const uint32_t n = rig.T * 24;
+    const float* src = cr.aabb_part + (size_t)i * rig.T * 6;  // [T][6]
+    const uint32_t n = rig.T * 6;
     float r = c < 3 ? __builtin_inff() : -__builtin_inff();
     for (uint32_t e = t; e < n; e += kAabbThreads) r = c < 3 ? fminf(r, src[e]) : fmaxf(r, src[e]);
     part[t] = r;
@@ -1015,6 +1174,10 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
     hipError_t e = hipSuccess;
     // tiles of kind 2 (short joint lists): the self-staging kernel unless it is switched off
     if (plan.v2 && (plan.kinds & 4u)) {
+        if (cr.fix) {
+            e = hipMemsetAsync(cr.fix, 0, 16, s);  // empty work list
+            if (e != hipSuccess) return e;
+        }
         const dim3 grid(8u * plan.tiles_per_chunk * plan.ranges_per_chunk2), block(kSkin2Threads);
         if (rig.K == 1) {
             if (plan.exact) hipLaunchKernelGGL((k_skin2<true, 1>), grid, block, plan.lds_bytes2, s, rig, cr, plan);
@@ -1024,6 +1187,17 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
             else hipLaunchKernelGGL((k_skin2<false, 2>), grid, block, plan.lds_bytes2, s, rig, cr, plan);
         }
         e = hipGetLastError();
+        if (e == hipSuccess && cr.fix && !(SKINRT_ABLATE & 32)) {  // what k_skin2 handed over (the count is on the device: fixed grid)
+            const dim3 fgrid(4096), fblock(256);
+            if (rig.K == 1) {
+                if (plan.exact) hipLaunchKernelGGL((k_skin_fix<true, 1>), fgrid, fblock, 0, s, rig, cr, plan);
+                else hipLaunchKernelGGL((k_skin_fix<false, 1>), fgrid, fblock, 0, s, rig, cr, plan);
+            } else {
+                if (plan.exact) hipLaunchKernelGGL((k_skin_fix<true, 2>), fgrid, fblock, 0, s, rig, cr, plan);
+                else hipLaunchKernelGGL((k_skin_fix<false, 2>), fgrid, fblock, 0, s, rig, cr, plan);
+            }
+            e = hipGetLastError();
+        }
     }
     if (e == hipSuccess && ((plan.kinds & 2u) || (!plan.v2 && (plan.kinds & 4u))))
         e = plan.exact ? launch_skin_k<true, true>(rig, cr, plan, s) : launch_skin_k<false, true>(rig, cr, plan, s);

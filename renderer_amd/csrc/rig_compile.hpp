@@ -35,8 +35,14 @@ struct MorphPair {
     uint16_t dense;
     uint32_t reserved;
 };
-constexpr uint32_t kSkin2Range = 128;         // instances per block of the self-staging skinning kernel
-constexpr uint32_t kSkin2PalLook = 2;         // its palette LDS-DMA runs this many instances ahead
+#ifndef SKINRT_RANGE2
+#define SKINRT_RANGE2 128
+#endif
+constexpr uint32_t kSkin2Range = SKINRT_RANGE2;         // instances per block of the self-staging skinning kernel
+#ifndef SKINRT_PAL_LOOK
+#define SKINRT_PAL_LOOK 3
+#endif
+constexpr uint32_t kSkin2PalLook = SKINRT_PAL_LOOK;         // its palette LDS-DMA runs this many instances ahead
 constexpr uint32_t kSkin2PalRing = kSkin2PalLook + 1;
 constexpr uint32_t kMorphWaveFloats = 576;    // one wave's share of a dense pair = one LDS slot
 constexpr uint32_t kMorphDenseMin = 57;       // touched vertices from which a pair is stored dense

@@ -3,7 +3,7 @@
 import csv, glob, os, sys, collections
 d = sys.argv[1]
 def short(n):
-    for k in ("k_skin", "k_pose_wave", "k_aabb_reduce", "k_sample_local", "k_propagate_lane", "k_palette", "k_fill_mw"):
+    for k in ("k_skin_fix", "k_skin2", "k_skin", "k_pose_wave", "k_propagate_quad", "k_aabb_reduce", "k_sample_local", "k_propagate_lane", "k_palette", "k_fill_mw"):
         if k in n: return k
     return n[:40]
 for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
