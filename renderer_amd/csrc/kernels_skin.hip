@@ -741,12 +741,15 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     const uint32_t JTP = 1u << plan.jt2_shift;
     const uint32_t M = rig.M;
     // LDS: block tables, then per wave {palette ring, morph slots}
-    uint4* hdr_s = reinterpret_cast<uint4*>(smem);                              // [128] instance headers, processing order
-    uint32_t* mask_s = reinterpret_cast<uint32_t*>(hdr_s + kSkin2Range);        // [128] active-pair mask per instance-in-range
-    uint16_t* perm_s = reinterpret_cast<uint16_t*>(mask_s + kSkin2Range);       // [128] processing order
-    MorphPair* pairs_s = reinterpret_cast<MorphPair*>(perm_s + kSkin2Range + 32);  // [max_pairs] (+32: keeps 16-byte alignment)
-    float* bb_s = reinterpret_cast<float*>(pairs_s + plan.max_pairs);              // [128][6] bounds per processing position
+    uint4* hdr_s = reinterpret_cast<uint4*>(smem);                              // [range] instance headers, processing order
+    MorphPair* pairs_s = reinterpret_cast<MorphPair*>(hdr_s + kSkin2Range);     // [max_pairs]
+    float* bb_s = reinterpret_cast<float*>(pairs_s + plan.max_pairs);           // [range][6] bounds per processing position
     float* wave_s = bb_s + kSkin2Range * 6;
+    // prologue scratch, overlaid on the wave areas (unused until the pipeline starts)
+    uint32_t* cnt_s = reinterpret_cast<uint32_t*>(wave_s);                      // [8] counters
+    uint32_t* mask_s = cnt_s + 8;                                               // [range] active-pair mask per instance-in-range
+    uint16_t* perm_s = reinterpret_cast<uint16_t*>(mask_s + kSkin2Range);       // [range] sorted order
+    uint16_t* start_s = perm_s + kSkin2Range;                                   // [runs] sorted position where run j starts
     const uint32_t pal_slot_f = JTP * 24;                                       // floats per palette slot
     const uint32_t per_wave_f = R * pal_slot_f + (M ? kMorphSlots * kMorphWaveFloats : 0u);
     float* pal_ring = wave_s + (size_t)wave * per_wave_f;                       // [R][JTP][6] f4
@@ -767,7 +770,6 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     // This kernel morphs from its two LDS slots only: an instance with 1 or 2 active pairs, both
     // dense.  Every other non-idle (tile, instance) — 3+ active pairs, a compacted pair, a tile with
     // more than 32 pairs — goes on the work list of k_skin_fix and is left out of this block's order.
-    uint32_t* cnt_s = reinterpret_cast<uint32_t*>(wave_s);      // [6], overlaid on the (still unused) wave area
     uint32_t my_mask = 0xffffffffu;  // padding and handed-over instances sort last
     {
         bool slow = false;
@@ -819,7 +821,6 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     // before they are read, and the ordinary palette wait then covers them — no store has to drain.
     // Runs that get no spacer (too few idle instances) request their pairs one instance ahead and
     // wait for all but that instance's last stores ("near" reload).
-    uint16_t* start_s = reinterpret_cast<uint16_t*>(cnt_s + 8); // [runs] sorted position where run j starts
     const bool in_range = tid < nproc;
     const uint32_t sm = in_range ? mask_s[perm_s[tid]] : 0xffffffffu;
     const uint32_t sprev = (in_range && tid) ? mask_s[perm_s[tid - 1]] : 0u;
@@ -853,6 +854,11 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
             near = (start && run > nsp) ? 1u : 0u;
         } else if (tid < z0) {
             fpos = tid;
+#ifdef SKINRT_ROTATE
+            // no morph run in this block: the order is free.  Start each block somewhere else, so that the
+            // blocks of an XCD do not walk the same instances in lockstep.
+            if (runs == 0) { fpos = tid + (tile * 29u + rng * 13u) % nproc; if (fpos >= nproc) fpos -= nproc; }
+#endif
         } else {
             const uint32_t idx = tid - z0, sj = idx / sp, within = idx - sj * sp;
             const uint32_t nxt = start_s[sj + 1];
@@ -1052,7 +1058,8 @@ __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdD
     constexpr int W = 4 * K;
     __shared__ f4 pal_s[2][128];
     __shared__ float part[4][6];
-    const uint32_t tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ MorphPair pairs_l[64];  // the tile's first 64 pair records
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t count = min(cr.fix[0], cr.fix_cap);
     const Outputs out{cr.pos, cr.nrm, cr.tan};
     const bool normalize = plan.normalize != 0;
@@ -1082,6 +1089,9 @@ __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdD
                 joff = tid < npieces ? rig.tile_joints[jstart + tid / 6] * 6 + tid % 6 : 0u;
                 pbeg = rig.tile_pair_start[tile];
                 pend = rig.tile_pair_start[tile + 1];
+                __syncthreads();  // the previous tile's records are no longer read
+                if (tid < min(pend - pbeg, 64u)) pairs_l[tid] = rig.pairs[pbeg + tid];
+                __syncthreads();
             }
             // stage this instance's palette rows; the buffers alternate, so the one barrier below
             // also separates the previous entry's reads of this buffer from these writes
@@ -1089,7 +1099,18 @@ __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdD
             if (tid < npieces) ps[tid] = pal_g[(size_t)inst * rig.J * 6 + joff];
             float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
             const float* mwg = cr.mw + (size_t)inst * M;
-            for (uint32_t q = pbeg; q < pend; ++q) {
+            // the first 64 pairs: one parallel fetch of their weights (lane q = pair q), then only the
+            // active ones are visited, ascending — not one dependent load chain per pair
+            const uint32_t np64 = min(pend - pbeg, 64u);
+            const float mwq = lane < np64 ? mwg[pairs_l[lane].target] : 0.0f;
+            for (uint64_t act = __ballot(mwq != 0.0f); act; act &= act - 1) {
+                const uint32_t q = (uint32_t)__builtin_ctzll(act);
+                const float mw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mwq), q));
+                const MorphPair mp = pairs_l[q];
+                const bool dense = mp.dense != 0;
+                morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
+            }
+            for (uint32_t q = pbeg + 64; q < pend; ++q) {
                 const MorphPair mp = rig.pairs[q];
                 const float mw = mwg[mp.target];
                 if (mw == 0.0f) continue;  // wave-uniform; a zero weight adds exactly 0

@@ -36,11 +36,11 @@ struct MorphPair {
     uint32_t reserved;
 };
 #ifndef SKINRT_RANGE2
-#define SKINRT_RANGE2 128
+#define SKINRT_RANGE2 120
 #endif
 constexpr uint32_t kSkin2Range = SKINRT_RANGE2;         // instances per block of the self-staging skinning kernel
 #ifndef SKINRT_PAL_LOOK
-#define SKINRT_PAL_LOOK 3
+#define SKINRT_PAL_LOOK 2
 #endif
 constexpr uint32_t kSkin2PalLook = SKINRT_PAL_LOOK;         // its palette LDS-DMA runs this many instances ahead
 constexpr uint32_t kSkin2PalRing = kSkin2PalLook + 1;
