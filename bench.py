@@ -188,7 +188,7 @@ def main():
                        "exact_arithmetic": args.exact, "parallelism": f"instances sharded x{n_gpus}"},
             "stage_ms": {"pose": float(stage[:, 0].mean()), "skin_morph": skin_ms,
                          "aabb_reduce": float(stage[:, 2].mean()), "device_span": float(stage[:, 3].mean())},
-            "roofline": {"bound": "hbm", "kernel": "k_skin (morph + linear-blend skinning)", "achieved": achieved / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "skin stage = k_skin2 + k_skin_fix (morph + linear-blend skinning + per-tile bounds)", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": skin_ms, "traffic": traffic},
             "rig_compile": {"tiles": info.tile_count, "max_tile_joints": info.max_tile_joints,

@@ -114,6 +114,28 @@ def test_c5_shape_reduced(oracle32, oracle64, exact):
         assert gap < 1e-4, "oracle gap itself unexpectedly large"
 
 
+@pytest.mark.parametrize("targets,frac,mode,zero", [
+    (6, 1.0, "dense", 0.5),     # every tile has 6 pairs: 0 ... 6 active per instance (slot path, hand-over, spacers, near reloads)
+    (40, 1.0, "dense", 0.9),    # more than 32 pairs per tile: every non-idle instance is handed to k_skin_fix
+    (8, 0.5, "dense", 0.2),     # few idle instances: runs without spacers
+    (12, 0.3, "sparse", 0.5),   # compacted pairs
+    (5, 1.0, "dense", 0.0),     # no idle instance at all, every instance has 5 active pairs
+    (3, 1.0, "dense", 0.97),    # almost everything idle
+])
+@pytest.mark.parametrize("exact", [1, 0])
+def test_morph_schedules(oracle32, targets, frac, mode, zero, exact):
+    """The self-staging kernel reorders a block's instances by their set of active morph pairs, deals
+    idle instances out as spacers, and hands instances it cannot serve from two LDS slots to
+    k_skin_fix: whatever the schedule, every instance must come out as the oracle computes it."""
+    spec = synth.scaled(synth.tiny_spec(seed=21), verts=700, targets=targets, target_frac=frac, target_mode=mode,
+                        morph_zero_frac=zero)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=300)   # 3 blocks per tile, the last one ragged
+    got = run_gpu(rig, crowd, exact_arithmetic=exact)
+    ref = run_oracle(oracle32, rig, crowd)
+    _check_all(got, ref, exact_skin=bool(exact), tag="morph:")
+
+
 def test_scattered_joints_use_global_palette_path(oracle32):
     """Worst-case locality: influences uniform over 300 joints -> tile joint lists exceed the LDS
     cap and the kernel gathers the palette from L2 instead.  Joint gathers must stay exact."""

@@ -1,20 +1,44 @@
 #!/usr/bin/env python3
-"""Summarise tools/prof.sh output: per-kernel avg duration and mean PMC counters per dispatch."""
+"""Summarise tools/prof.sh output: per-kernel duration (from the kernel trace) and mean PMC counters
+per dispatch.  Dispatches of the skin kernels that precede the first pose kernel belong to the
+placement search at crowd creation (all morph weights zero, see api.hip tune_output_placement):
+they are not frames and are left out.  `--csv` prints the per-kernel table as CSV."""
 import csv, glob, os, sys, collections
 d = sys.argv[1]
+as_csv = "--csv" in sys.argv
+KERNELS = ("k_skin_fix", "k_skin2", "k_skin", "k_pose_wave", "k_propagate_quad", "k_aabb_reduce", "k_sample_local",
+           "k_palette", "k_fill_mw")
 def short(n):
-    for k in ("k_skin_fix", "k_skin2", "k_skin", "k_pose_wave", "k_propagate_quad", "k_aabb_reduce", "k_sample_local", "k_propagate_lane", "k_palette", "k_fill_mw"):
+    for k in KERNELS:
         if k in n: return k
     return n[:40]
-for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    print("== kernel stats", f)
-    for r in csv.DictReader(open(f)):
-        print(f"  {short(r['Name']):18s} calls={r['Calls']:>5s} avg_ns={float(r['AverageNs']):>12.0f} total%={r['Percentage']}")
+def frames_only(rows, name_key, id_key):
+    """drop skin-kernel dispatches issued before the first pose dispatch"""
+    rows = sorted(rows, key=lambda r: int(r[id_key]))
+    first_pose = next((int(r[id_key]) for r in rows if short(r[name_key]) in ("k_pose_wave", "k_sample_local")), None)
+    if first_pose is None: return rows
+    return [r for r in rows if not (short(r[name_key]).startswith("k_skin") and int(r[id_key]) < first_pose)]
+for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    rows = frames_only(list(csv.DictReader(open(f))), "Kernel_Name", "Dispatch_Id")
+    acc = collections.defaultdict(list)
+    for r in rows: acc[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    tot = sum(sum(v) for v in acc.values())
+    if as_csv:
+        print("Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage")
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+            print(f"{k},{len(v)},{sum(v)},{sum(v)/len(v):.0f},{min(v)},{max(v)},{100.0*sum(v)/tot:.3f}")
+        sys.exit(0)
+    print("== kernel durations (frames only)", f)
+    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        print(f"  {k:18s} calls={len(v):5d} avg_ns={sum(v)/len(v):12.0f} min_ns={min(v):10d} max_ns={max(v):10d} total%={100.0*sum(v)/tot:.2f}")
+    skin = [acc.get("k_skin2", []), acc.get("k_skin_fix", []), acc.get("k_skin", [])]
+    per_frame = sum(sum(v) / len(v) for v in skin if v)
+    print(f"  skin stage per frame (k_skin2 + k_skin_fix + k_skin averages): {per_frame / 1e6:.3f} ms")
 for p in sorted(glob.glob(os.path.join(d, "pmc*"))):
     if not os.path.isdir(p): continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(p, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
+        for r in frames_only(list(csv.DictReader(open(f))), "Kernel_Name", "Dispatch_Id"):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("==", os.path.basename(p))
     for k, cs in acc.items():

@@ -7,5 +7,6 @@ TAG=$1; shift
 tools/prof.sh $TAG "$@" || exit 1
 python3 tools/prof_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.txt || exit 1
 python3 tools/make_traffic.py gpurun_out/$TAG "$@" > gpurun_out/$TAG/traffic.json || exit 1
-cat gpurun_out/$TAG/summary.txt | grep -E "k_skin|k_pose|k_aabb|==" | head -40
+python3 tools/prof_summary.py gpurun_out/$TAG --csv > gpurun_out/$TAG/kernel_stats.csv
+grep -E "k_skin|k_pose|k_aabb|==|skin stage" gpurun_out/$TAG/summary.txt | head -40
 cat gpurun_out/$TAG/traffic.json
