@@ -85,7 +85,7 @@ struct skinrt_crowd {
         c.pos = pos.as<float>(); c.nrm = nrm.as<float>(); c.tan = tan.as<float>();
         c.aabb_part = aabb_part.as<float>(); c.aabb = aabb.as<float>();
         c.fix = fix.p ? fix.as<uint32_t>() : nullptr;
-        c.fix_cap = fix.p ? (uint32_t)((fix.bytes - 16) / 8) : 0u;
+        c.fix_inst = fix.p ? fix.as<uint32_t>() + (rig->host.T + 3) / 4 * 4 : nullptr;
         return c;
     }
 };
@@ -390,7 +390,7 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
         {&c->world, I * h.N * 48}, {&c->palette, I * h.J * 96}, {&c->keyidx, I * h.Cmax * 4},
         {&c->pos, I * h.V * 12}, {&c->nrm, I * h.V * 12}, {&c->tan, I * h.V * 12},
         {&c->aabb_part, I * h.T * 24}, {&c->aabb, I * 24},      // bounds per (instance, tile)
-        {&c->fix, h.M ? 16 + I * h.T * 8 : 0},                   // work list of k_skin_fix
+        {&c->fix, h.M ? ((size_t)h.T + 3) / 4 * 16 + I * h.T * 4 : 0},  // per-tile work lists of k_skin_fix
     };
     for (auto& it : plan) {
         hipError_t e = it.b->alloc(it.n);

@@ -51,9 +51,10 @@ struct CrowdDev {
     float* aabb_part;      // [I][T][6]
     float* aabb;           // [I][6]
     // (tile, instance) pairs the self-staging skin kernel hands to k_skin_fix (3+ active morph
-    // pairs, compacted pairs, tiles with more than 32 pairs): fix[0] = count, entries from fix[4]
-    uint32_t* fix;         // [4 + 2 * fix_cap] or nullptr (rig without morph targets)
-    uint32_t fix_cap;      // T * I: every pair fits
+    // pairs, compacted pairs, tiles with more than 32 pairs), kept per tile:
+    // fix[tile] = number of instances handed over, fix_inst[tile * I + k] = the k-th of them
+    uint32_t* fix;         // [T] counters, or nullptr (rig without morph targets)
+    uint32_t* fix_inst;    // [T][I]
 };
 
 // How the skinning grid is cut (computed once per crowd by plan_skin()).

@@ -789,11 +789,11 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         if (bslow) {  // wave-uniform
             const uint32_t n = (uint32_t)__popcll(bslow);
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(cr.fix, n);
+            if (lane == 0) base = atomicAdd(cr.fix + tile, n);
             base = __builtin_amdgcn_readfirstlane(base);
             if (slow) {
                 const uint32_t e = base + (uint32_t)__popcll(bslow & ((1ull << lane) - 1ull));
-                if (e < cr.fix_cap) *reinterpret_cast<uint2*>(cr.fix + 4 + 2 * (size_t)e) = make_uint2(tile, i0 + tid);
+                if (e < cr.I) cr.fix_inst[(size_t)tile * cr.I + e] = i0 + tid;  // (an instance is handed over at most once per tile)
                 my_mask = 0xffffffffu;
             }
         }
@@ -1060,50 +1060,71 @@ __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdD
     __shared__ float part[4][6];
     __shared__ MorphPair pairs_l[64];  // the tile's first 64 pair records
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t count = min(cr.fix[0], cr.fix_cap);
+    const uint32_t tile = blockIdx.x;
+    const uint32_t count = min(cr.fix[tile], cr.I);
+    if (blockIdx.y * kFixChunk >= count) return;
     const Outputs out{cr.pos, cr.nrm, cr.tan};
     const bool normalize = plan.normalize != 0;
     const uint32_t M = rig.M;
     const f4* pal_g = reinterpret_cast<const f4*>(cr.palette);
-    for (uint32_t e0 = blockIdx.x * kFixChunk; e0 < count; e0 += gridDim.x * kFixChunk) {
+    // the block's tile: vertex data, joint list, pair records — loaded once
+    const bool valid = tile * TV + tid < rig.V;
+    float p0[3], n0[3], t0[3], w[W];
+    uint32_t li[W];
+    {
+        const float* b = rig.base + (size_t)tile * 9 * TV + tid;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { p0[x] = b[x * TV]; n0[x] = b[(3 + x) * TV]; t0[x] = b[(6 + x) * TV]; }
+        const float* wt = rig.wts + (size_t)tile * W * TV + tid;
+        const uint16_t* lp = rig.lidx + (size_t)tile * W * TV + tid;
+#pragma unroll
+        for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
+    }
+    const uint32_t jstart = rig.tile_joint_start[tile];
+    const uint32_t npieces = (rig.tile_joint_start[tile + 1] - jstart) * 6;  // <= 126 for k_skin2's tiles
+    const uint32_t joff = tid < npieces ? rig.tile_joints[jstart + tid / 6] * 6 + tid % 6 : 0u;
+    const uint32_t pbeg = rig.tile_pair_start[tile], pend = rig.tile_pair_start[tile + 1];
+    if (tid < min(pend - pbeg, 64u)) pairs_l[tid] = rig.pairs[pbeg + tid];
+    __syncthreads();
+    const uint32_t* list = cr.fix_inst + (size_t)tile * cr.I;
+    uint32_t flip = 0;  // palette staging buffer in use
+    for (uint32_t e0 = blockIdx.y * kFixChunk; e0 < count; e0 += gridDim.y * kFixChunk) {
         const uint32_t e1 = min(count, e0 + kFixChunk);
-        uint32_t cur_tile = 0xffffffffu, jstart = 0, npieces = 0, pbeg = 0, pend = 0, joff = 0;
-        bool valid = false;
-        float p0[3], n0[3], t0[3], w[W];
-        uint32_t li[W];
+        // the chunk's instances in one load (lane k = entry e0 + k)
+        uint32_t ents = 0;
+        if (e0 + lane < e1 && lane < kFixChunk) ents = list[e0 + lane];
+        // palette piece and pair weights of the NEXT entry, requested while the current one is worked on
+        f4 piece_next = {0.0f, 0.0f, 0.0f, 0.0f};
+        float mwq_next = 0.0f;
+        bool have_next = false;
         for (uint32_t e = e0; e < e1; ++e) {
-            const uint2 ent = *reinterpret_cast<const uint2*>(cr.fix + 4 + 2 * (size_t)e);
-            const uint32_t tile = __builtin_amdgcn_readfirstlane(ent.x), inst = __builtin_amdgcn_readfirstlane(ent.y);
-            if (tile != cur_tile) {  // block-uniform
-                cur_tile = tile;
-                valid = tile * TV + tid < rig.V;
-                const float* b = rig.base + (size_t)tile * 9 * TV + tid;
-#pragma unroll
-                for (int x = 0; x < 3; ++x) { p0[x] = b[x * TV]; n0[x] = b[(3 + x) * TV]; t0[x] = b[(6 + x) * TV]; }
-                const float* wt = rig.wts + (size_t)tile * W * TV + tid;
-                const uint16_t* lp = rig.lidx + (size_t)tile * W * TV + tid;
-#pragma unroll
-                for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
-                jstart = rig.tile_joint_start[tile];
-                npieces = (rig.tile_joint_start[tile + 1] - jstart) * 6;  // <= 126 for k_skin2's tiles
-                joff = tid < npieces ? rig.tile_joints[jstart + tid / 6] * 6 + tid % 6 : 0u;
-                pbeg = rig.tile_pair_start[tile];
-                pend = rig.tile_pair_start[tile + 1];
-                __syncthreads();  // the previous tile's records are no longer read
-                if (tid < min(pend - pbeg, 64u)) pairs_l[tid] = rig.pairs[pbeg + tid];
-                __syncthreads();
-            }
+            const uint32_t inst = __builtin_amdgcn_readlane(ents, e - e0);
             // stage this instance's palette rows; the buffers alternate, so the one barrier below
             // also separates the previous entry's reads of this buffer from these writes
-            f4* ps = pal_s[(e - e0) & 1];
-            if (tid < npieces) ps[tid] = pal_g[(size_t)inst * rig.J * 6 + joff];
-            float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
+            f4* ps = pal_s[flip];
+            flip ^= 1u;
             const float* mwg = cr.mw + (size_t)inst * M;
             // the first 64 pairs: one parallel fetch of their weights (lane q = pair q), then only the
             // active ones are visited, ascending — not one dependent load chain per pair
             const uint32_t np64 = min(pend - pbeg, 64u);
-            const float mwq = lane < np64 ? mwg[pairs_l[lane].target] : 0.0f;
-            for (uint64_t act = __ballot(mwq != 0.0f); act; act &= act - 1) {
+            f4 piece = piece_next;
+            float mwq = mwq_next;
+            if (!have_next) {
+                if (tid < npieces) piece = pal_g[(size_t)inst * rig.J * 6 + joff];
+                mwq = lane < np64 ? mwg[pairs_l[lane].target] : 0.0f;
+            }
+            have_next = e + 1 < e1;
+            if (have_next) {
+                const uint32_t inst2 = __builtin_amdgcn_readlane(ents, (e + 1 - e0) & 63u);
+                if (tid < npieces) piece_next = pal_g[(size_t)inst2 * rig.J * 6 + joff];
+                mwq_next = lane < np64 ? cr.mw[(size_t)inst2 * M + pairs_l[lane].target] : 0.0f;
+            }
+            if (tid < npieces) ps[tid] = piece;
+            float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
+#ifndef SKINRT_FIX_ABLATE
+#define SKINRT_FIX_ABLATE 0
+#endif
+            for (uint64_t act = (SKINRT_FIX_ABLATE & 1) ? 0ull : __ballot(mwq != 0.0f); act; act &= act - 1) {
                 const uint32_t q = (uint32_t)__builtin_ctzll(act);
                 const float mw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mwq), q));
                 const MorphPair mp = pairs_l[q];
@@ -1119,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdD
             }
             __syncthreads();
             float op[3];
-            skin_store<EXACT, K>(LdsPal{ps}, w, li, p, n, t, normalize, valid, out, (size_t)inst * rig.V * 3,
+            skin_store<EXACT, K>(LdsPal{ps}, w, li, p, n, t, normalize, valid && !(SKINRT_FIX_ABLATE & 2), out, (size_t)inst * rig.V * 3,
                                  (tile * TV + tid) * 12, op);
             if (plan.aabb) {
                 float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
@@ -1196,7 +1217,7 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
     // tiles of kind 2 (short joint lists): the self-staging kernel unless it is switched off
     if (plan.v2 && (plan.kinds & 4u)) {
         if (cr.fix) {
-            e = hipMemsetAsync(cr.fix, 0, 16, s);  // empty work list
+            e = hipMemsetAsync(cr.fix, 0, (size_t)rig.T * 4, s);  // empty work lists
             if (e != hipSuccess) return e;
         }
         const dim3 grid(8u * plan.tiles_per_chunk * plan.ranges_per_chunk2), block(kSkin2Threads);
@@ -1209,7 +1230,10 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         }
         e = hipGetLastError();
         if (e == hipSuccess && cr.fix && !(SKINRT_ABLATE & 32)) {  // what k_skin2 handed over (the count is on the device: fixed grid)
-            const dim3 fgrid(4096), fblock(256);
+            // x: tile, y: chunk lane.  Lists are uneven (tiles with many pairs hand over most), so there are
+            // enough lanes that the longest list is a few chunks per block; blocks past a list's end leave at once
+            const uint32_t lanes = std::min((cr.I + kFixChunk - 1) / kFixChunk, std::max(1u, 32768u / rig.T));
+            const dim3 fgrid(rig.T, lanes), fblock(256);
             if (rig.K == 1) {
                 if (plan.exact) hipLaunchKernelGGL((k_skin_fix<true, 1>), fgrid, fblock, 0, s, rig, cr, plan);
                 else hipLaunchKernelGGL((k_skin_fix<false, 1>), fgrid, fblock, 0, s, rig, cr, plan);
