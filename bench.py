@@ -82,7 +82,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, choices=[None, "c2", "c3", "c4", "c5"])
     ap.add_argument("--instances", type=int, default=None, help="override the TOTAL instance count")
     ap.add_argument("--gather-vertices", action="store_true", help="also all-gather position buffers (xGMI-bound)")
