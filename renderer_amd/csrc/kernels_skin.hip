@@ -1,15 +1,16 @@
 // kernels_skin.hip — morph-target blending + linear-blend skinning (+ per-tile bounds) for
 // gfx950.
 //
-// Shape: one 256-thread block = one tile of 256 vertices x one range of instances.  A thread
-// keeps ITS vertex (base position/normal/tangent, 4K weights, 4K tile-local joint indices) in
-// registers for the whole block and loops over the instances, so the shared mesh is read once
-// per range and every instance costs 36 B of stores per vertex.  The joint palette of a batch of
-// instances is staged into LDS (only the joints the tile references: rig_compile builds per-tile
-// joint lists and rewrites the vertex indices to list positions); each influence is then six
-// ds_read_b128 whose register pairs feed v_pk_fma_f32 directly.  Morph targets are applied by a
-// wave-uniform loop over the tile's (tile, target) pairs that have a non-zero weight for the
-// instance; pair data streams from L2 (the block -> XCD mapping keeps a tile's blocks on one XCD).
+// Shape: one block = one tile of 256 vertices x one range of instances.  A thread keeps ITS
+// vertex (base position/normal/tangent, 4K weights, 4K tile-local joint indices) in registers for
+// the whole block and loops over the instances, so the shared mesh is read once per range and
+// every instance costs 36 B of stores per vertex.  Only the joints the tile references are staged
+// in LDS (rig_compile builds per-tile joint lists and rewrites the vertex indices to list
+// positions); morph deltas of the (tile, target) pairs with a non-zero weight reach the waves
+// through LDS slots.  Three kernels share the arithmetic below:
+//   k_skin2     tiles with <= 21 joints, <= 2 weight sets: four self-staging waves per block
+//   k_skin_fix  the (tile, instance) pairs k_skin2 hands over (3+ active pairs, compacted pairs)
+//   k_skin      everything else: four compute waves + one loader wave
 //
 // Arithmetic order is the WGSL's (renderer/src/shader/shader.wgsl:127-141, :159-163):
 //   S  = ((w0*M[j0] + w1*M[j1]) + w2*M[j2]) + w3*M[j3]   (further weight sets continue the chain)
@@ -31,8 +32,9 @@ __device__ unsigned long long g_stamps[16];
 #endif
 
 // Diagnostic builds only (-DSKINRT_ABLATE=bits): 1 = skip the morph arithmetic, 2 = skip the morph
-// LDS-DMA, 4 = loader reports no active pairs, 8 = dense deltas from registers (no LDS read),
-// 16 = dense deltas read but not applied.  Results are wrong by design; timing experiments.
+// LDS-DMA, 4 = no instance has an active pair, 8 = dense deltas from registers (no LDS read),
+// 16 = dense deltas read but not applied, 32 = k_skin_fix is not launched.  -DSKINRT_FIX_ABLATE=bits:
+// 1 = k_skin_fix skips its delta loads, 2 = its stores.  Results are wrong by design; timing experiments.
 #ifndef SKINRT_ABLATE
 #define SKINRT_ABLATE 0
 #endif
@@ -662,14 +664,17 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
 // has no register destination and therefore needs no wait until the data is used:
 //   * the palette rows of the tile's joints for instance pos+2 are requested at the top of
 //     instance pos into the wave's own ring of 3 palette slots;
-//   * the morph pairs of instance pos+1 are requested in the middle of instance pos (as in k_skin).
+//   * the morph pairs of a run of instances with the same active set are requested at the first idle
+//     instance of the spacer in front of the run (see the prologue), or, without a spacer, in the
+//     middle of the previous instance (as in k_skin).
 // All waits are COUNTED (vmcnt is in issue order, loads and stores alike): every instance issues at
 // least `spi` stores, so "palette of this instance has landed" is s_waitcnt vmcnt(2 * spi), and the
 // stores of the last two instances stay in flight.  With no loader the block is 256 threads, five
 // blocks = 20 compute waves per CU instead of 16 (throughput follows the number of compute waves).
-// Per-block tables (instance order, headers with the first two active pairs' weights) are built
-// once in the prologue, before any store exists.  Tiles with more than 21 joints (their palette
-// pieces do not fit two DMA instructions) and rigs with 3-4 weight sets stay on k_skin.
+// Per-block tables (instance order, headers with the first two active pairs' weights, one bounds
+// cell per processing position) are built once in the prologue, before any store exists.
+// Instances that need more than the two slots go to k_skin_fix.  Tiles with more than 21 joints
+// (their palette pieces do not fit two DMA instructions) and rigs with 3-4 weight sets stay on k_skin.
 
 #define SKINRT_GLDS_AT(VOFF, GBASE, LDSB)                                                               \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                       \
