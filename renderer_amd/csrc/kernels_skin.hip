@@ -690,7 +690,9 @@ __device__ __forceinline__ void wait_vmcnt_dyn(uint32_t n) {
         case 0: wait_vmcnt<0>(); break;
         case 1: wait_vmcnt<1>(); break;
         case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
         case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
         case 6: wait_vmcnt<6>(); break;
         case 8: wait_vmcnt<8>(); break;
         case 9: wait_vmcnt<9>(); break;
@@ -1065,9 +1067,16 @@ __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdD
     __shared__ float part[4][6];
     __shared__ MorphPair pairs_l[64];  // the tile's first 64 pair records
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t tile = blockIdx.x;
+    // block -> (tile, chunk lane): consecutive block ids go round-robin to the 8 XCDs; every block of
+    // a tile gets the same id modulo 8 (tile % 8: neighbouring tiles, which tend to be equally busy,
+    // go to different XCDs), so the tile's deltas are fetched into ONE L2
+    const uint32_t tiles_per_xcd = (rig.T + 7) / 8;
+    const uint32_t kb = blockIdx.x >> 3;
+    const uint32_t tile = (kb % tiles_per_xcd) * 8 + (blockIdx.x & 7);
+    const uint32_t chunk_lane = kb / tiles_per_xcd, chunk_lanes = gridDim.x / (8 * tiles_per_xcd);
+    if (tile >= rig.T) return;
     const uint32_t count = min(cr.fix[tile], cr.I);
-    if (blockIdx.y * kFixChunk >= count) return;
+    if (chunk_lane * kFixChunk >= count) return;
     const Outputs out{cr.pos, cr.nrm, cr.tan};
     const bool normalize = plan.normalize != 0;
     const uint32_t M = rig.M;
@@ -1093,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdD
     __syncthreads();
     const uint32_t* list = cr.fix_inst + (size_t)tile * cr.I;
     uint32_t flip = 0;  // palette staging buffer in use
-    for (uint32_t e0 = blockIdx.y * kFixChunk; e0 < count; e0 += gridDim.y * kFixChunk) {
+    for (uint32_t e0 = chunk_lane * kFixChunk; e0 < count; e0 += chunk_lanes * kFixChunk) {
         const uint32_t e1 = min(count, e0 + kFixChunk);
         // the chunk's instances in one load (lane k = entry e0 + k)
         uint32_t ents = 0;
@@ -1235,10 +1244,10 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         }
         e = hipGetLastError();
         if (e == hipSuccess && cr.fix && !(SKINRT_ABLATE & 32)) {  // what k_skin2 handed over (the count is on the device: fixed grid)
-            // x: tile, y: chunk lane.  Lists are uneven (tiles with many pairs hand over most), so there are
+            // one block per (tile, chunk lane).  Lists are uneven (tiles with many pairs hand over most), so there are
             // enough lanes that the longest list is a few chunks per block; blocks past a list's end leave at once
             const uint32_t lanes = std::min((cr.I + kFixChunk - 1) / kFixChunk, std::max(1u, 32768u / rig.T));
-            const dim3 fgrid(rig.T, lanes), fblock(256);
+            const dim3 fgrid(8u * ((rig.T + 7) / 8) * lanes), fblock(256);
             if (rig.K == 1) {
                 if (plan.exact) hipLaunchKernelGGL((k_skin_fix<true, 1>), fgrid, fblock, 0, s, rig, cr, plan);
                 else hipLaunchKernelGGL((k_skin_fix<false, 1>), fgrid, fblock, 0, s, rig, cr, plan);

@@ -36,7 +36,7 @@ struct MorphPair {
     uint32_t reserved;
 };
 #ifndef SKINRT_RANGE2
-#define SKINRT_RANGE2 120
+#define SKINRT_RANGE2 80
 #endif
 constexpr uint32_t kSkin2Range = SKINRT_RANGE2;         // instances per block of the self-staging skinning kernel
 #ifndef SKINRT_PAL_LOOK
