@@ -757,6 +757,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     uint32_t* mask_s = cnt_s + 8;                                               // [range] active-pair mask per instance-in-range
     uint16_t* perm_s = reinterpret_cast<uint16_t*>(mask_s + kSkin2Range);       // [range] sorted order
     uint16_t* start_s = perm_s + kSkin2Range;                                   // [runs] sorted position where run j starts
+    float2* w12_s = reinterpret_cast<float2*>(start_s + kSkin2Range);           // [range] weights of the first two active pairs
     const uint32_t pal_slot_f = JTP * 24;                                       // floats per palette slot
     const uint32_t per_wave_f = R * pal_slot_f + (M ? kMorphSlots * kMorphWaveFloats : 0u);
     float* pal_ring = wave_s + (size_t)wave * per_wave_f;                       // [R][JTP][6] f4
@@ -780,14 +781,30 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     uint32_t my_mask = 0xffffffffu;  // padding and handed-over instances sort last
     {
         bool slow = false;
+        float w_first = 0.0f, w_second = 0.0f;
         if (tid < nin) {
             my_mask = 0;
             uint32_t sparse = 0;
             const float* mwg = cr.mw + (size_t)(i0 + tid) * M;
-            for (uint32_t q = 0; q < np; ++q) {
-                const MorphPair mp = pairs_s[q];
-                if (mwg[mp.target] != 0.0f) my_mask |= 1u << min(q, 31u);
-                if (!mp.dense) sparse |= 1u << min(q, 31u);
+            for (uint32_t q0 = 0; q0 < np; q0 += 4) {  // four weights in flight: one memory round trip per four pairs
+                MorphPair mp[4];
+                float wq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    mp[u] = pairs_s[min(q0 + u, np - 1)];
+                    wq[u] = mwg[mp[u].target];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (q0 + u >= np) break;
+                    const uint32_t bit = 1u << min(q0 + u, 31u);
+                    if (wq[u] != 0.0f) {
+                        // the first two active pairs' weights go into the instance's header later
+                        if (my_mask == 0) w_first = wq[u]; else if ((my_mask & (my_mask - 1)) == 0) w_second = wq[u];
+                        my_mask |= bit;
+                    }
+                    if (!mp[u].dense) sparse |= bit;
+                }
             }
             slow = my_mask != 0 && (!exact_mask || __popc(my_mask) > 2 || (my_mask & sparse) != 0);
             if (SKINRT_ABLATE & 4) { slow = false; my_mask = 0; }
@@ -805,7 +822,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
             }
         }
         if (lane == 0 && wave < 2) cnt_s[4 + wave] = (uint32_t)__popcll(bslow);
-        if (tid < kSkin2Range) mask_s[tid] = my_mask;
+        if (tid < kSkin2Range) { mask_s[tid] = my_mask; w12_s[tid] = make_float2(w_first, w_second); }
     }
     __syncthreads();
     const uint32_t nproc = nin - cnt_s[4] - cnt_s[5];  // instances this block processes itself
@@ -879,10 +896,10 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
             q1 = (uint32_t)__ffs((int)m) - 1;
             const uint32_t m2 = m & (m - 1);
             q2 = m2 ? (uint32_t)__ffs((int)m2) - 1 : q1;
-            const MorphPair p1 = pairs_s[q1], p2 = pairs_s[q2];
             if (!pf) {
-                w1 = cr.mw[(size_t)inst * M + p1.target];
-                w2 = cr.mw[(size_t)inst * M + p2.target];
+                const float2 w12 = w12_s[k];
+                w1 = w12.x;
+                w2 = na >= 2 ? w12.y : w12.x;  // one active pair: both header weights name it (as q2 = q1)
             }
         }
         const uint32_t x = pf ? ((1u << 10) | (na << 11) | (q1 << 16) | (q2 << 24))
@@ -1152,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdD
                 const bool dense = mp.dense != 0;
                 morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
             }
-            __syncthreads();
+            lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
             float op[3];
             skin_store<EXACT, K>(LdsPal{ps}, w, li, p, n, t, normalize, valid && !(SKINRT_FIX_ABLATE & 2), out, (size_t)inst * rig.V * 3,
                                  (tile * TV + tid) * 12, op);
@@ -1163,7 +1180,7 @@ __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdD
                     float* dst = part[wave];
                     dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = b0; dst[4] = b1; dst[5] = b2;
                 }
-                __syncthreads();
+                lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
                 if (tid < 6) {
                     float r = part[0][tid];
                     for (int q = 1; q < 4; ++q) r = tid < 3 ? fminf(r, part[q][tid]) : fmaxf(r, part[q][tid]);
