@@ -878,11 +878,6 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
             near = (start && run > nsp) ? 1u : 0u;
         } else if (tid < z0) {
             fpos = tid;
-#ifdef SKINRT_ROTATE
-            // no morph run in this block: the order is free.  Start each block somewhere else, so that the
-            // blocks of an XCD do not walk the same instances in lockstep.
-            if (runs == 0) { fpos = tid + (tile * 29u + rng * 13u) % nproc; if (fpos >= nproc) fpos -= nproc; }
-#endif
         } else {
             const uint32_t idx = tid - z0, sj = idx / sp, within = idx - sj * sp;
             const uint32_t nxt = start_s[sj + 1];
