@@ -154,10 +154,17 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
     p.kinds = (r.tile_kind_count[0] ? 1u : 0u) | (r.tile_kind_count[1] ? 2u : 0u) | (r.tile_kind_count[2] ? 4u : 0u);
     p.v2 = (cfg.skin_path == 0 && r.K <= 2 && r.tile_kind_count[2] > 0) ? 1 : 0;
     {
-        p.jt2_shift = std::min<uint32_t>(p.jt_shift, 5);  // kind-2 tiles have at most 21 joints
-        const uint32_t per_wave = kSkin2PalRing * (96u << p.jt2_shift) + (r.M ? kMorphSlots * kMorphWaveFloats * 4 : 0);
+        p.jt2 = std::max<uint32_t>(1, std::min<uint32_t>(r.max_tile_joints2, 21));
+        const uint32_t slots = r.M ? kMorphSlots * kMorphWaveFloats * 4 : 0;
         const uint32_t tables = kSkin2Range * (16 + 24) + p.max_pairs * 16;  // headers, bounds cells, pair records
-        p.lds_bytes2 = tables + 4 * per_wave;
+        // the prologue's scratch (counters, masks, order, run starts, header weights) is overlaid on the wave areas
+        const uint32_t scratch = 32 + kSkin2Range * (4 + 2 + 2 + 8) + 64;
+        auto lds_for = [&](uint32_t look) { return tables + std::max(4 * ((look + 1) * 96u * p.jt2 + slots), scratch); };
+        // blocks per CU the LDS allows (at most 7: the register budget); two instances of lookahead
+        // unless one buys another resident block
+        auto blocks_for = [&](uint32_t look) { return std::min<uint32_t>(7, (160u * 1024) / lds_for(look)); };
+        p.look2 = blocks_for(1) > blocks_for(2) ? 1 : 2;
+        p.lds_bytes2 = lds_for(p.look2);
         if (p.lds_bytes2 > 64 * 1024) p.v2 = 0;
         uint64_t r2 = ((uint64_t)I * std::max<uint32_t>(1, r.T) + want_blocks - 1) / want_blocks;
         p.range2 = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(r2, 1), kSkin2Range);

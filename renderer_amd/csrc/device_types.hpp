@@ -83,7 +83,8 @@ struct SkinPlan {
     uint32_t ranges_per_chunk2;  // ceil(ranges2 / (8 / tile_chunks))
     uint32_t lds_bytes2;         // dynamic LDS per k_skin2 block
     uint32_t kinds;              // bit k set: the rig has tiles of kind k
-    uint32_t jt2_shift;          // log2 of k_skin2's padded tile joint-list length (<= 5)
+    uint32_t jt2;                // k_skin2: joints per palette slot = longest joint list among its tiles (<= 21)
+    uint32_t look2;              // k_skin2: palette LDS-DMA runs this many instances ahead (1 or 2); ring = look2 + 1 slots
 };
 
 enum PosePath : uint32_t { kPoseWave = 0, kPoseSplit = 1 };

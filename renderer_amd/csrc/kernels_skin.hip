@@ -728,12 +728,12 @@ __device__ __forceinline__ void wave_minmax6(float& a0, float& a1, float& a2, fl
 
 constexpr uint32_t kSkin2Threads = 256;
 
-template <bool EXACT, int K>
+template <bool EXACT, int K, int LOOK>
 __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
-    constexpr uint32_t L = kSkin2PalLook, R = kSkin2PalRing;
+    constexpr uint32_t L = LOOK, R = L + 1;  // palette lookahead (plan.look2) and ring slots
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t xcd = blockIdx.x & 7, kblk = blockIdx.x >> 3;
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     const uint32_t i0 = rng * plan.range2;
     const uint32_t i1 = min(cr.I, i0 + plan.range2);
     const uint32_t nin = i1 - i0;  // <= kSkin2Range
-    const uint32_t JTP = 1u << plan.jt2_shift;
+    const uint32_t JTP = plan.jt2;  // joints per palette slot
     const uint32_t M = rig.M;
     // LDS: block tables, then per wave {palette ring, morph slots}
     uint4* hdr_s = reinterpret_cast<uint4*>(smem);                              // [range] instance headers, processing order
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     __syncthreads();  // headers visible
 
     // ---------------- per-wave pipeline ----------------
-    for (uint32_t q = 0; q < min(L, nproc); ++q) pal_dma(__builtin_amdgcn_readfirstlane(hdr_s[q].y), q % R);
+    for (uint32_t q = 0; q < min(L, nproc); ++q) pal_dma(__builtin_amdgcn_readfirstlane(hdr_s[q].y), q);  // q < L < R
     uint32_t hx, hi, hz, hw;
     {
         const uint4 h0 = hdr_s[0];
@@ -1236,7 +1236,7 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         (uint64_t)plan.ranges_per_chunk * (8 / plan.tile_chunks) < plan.ranges)
         return hipErrorInvalidValue;
     if (plan.v2 && (plan.range2 == 0 || plan.range2 > kSkin2Range || (uint64_t)plan.ranges2 * plan.range2 < cr.I ||
-                    plan.lds_bytes2 > 64 * 1024 || rig.K > 2 || plan.jt2_shift > 5 ||
+                    plan.lds_bytes2 > 64 * 1024 || rig.K > 2 || plan.jt2 == 0 || plan.jt2 > 21 || plan.look2 < 1 || plan.look2 > 2 ||
                     (uint64_t)plan.ranges_per_chunk2 * (8 / plan.tile_chunks) < plan.ranges2))
         return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
@@ -1247,13 +1247,15 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
             if (e != hipSuccess) return e;
         }
         const dim3 grid(8u * plan.tiles_per_chunk * plan.ranges_per_chunk2), block(kSkin2Threads);
-        if (rig.K == 1) {
-            if (plan.exact) hipLaunchKernelGGL((k_skin2<true, 1>), grid, block, plan.lds_bytes2, s, rig, cr, plan);
-            else hipLaunchKernelGGL((k_skin2<false, 1>), grid, block, plan.lds_bytes2, s, rig, cr, plan);
+#define SKINRT_LAUNCH2(EX, KK, LL) hipLaunchKernelGGL((k_skin2<EX, KK, LL>), grid, block, plan.lds_bytes2, s, rig, cr, plan)
+        if (plan.look2 == 1) {
+            if (rig.K == 1) { if (plan.exact) SKINRT_LAUNCH2(true, 1, 1); else SKINRT_LAUNCH2(false, 1, 1); }
+            else { if (plan.exact) SKINRT_LAUNCH2(true, 2, 1); else SKINRT_LAUNCH2(false, 2, 1); }
         } else {
-            if (plan.exact) hipLaunchKernelGGL((k_skin2<true, 2>), grid, block, plan.lds_bytes2, s, rig, cr, plan);
-            else hipLaunchKernelGGL((k_skin2<false, 2>), grid, block, plan.lds_bytes2, s, rig, cr, plan);
+            if (rig.K == 1) { if (plan.exact) SKINRT_LAUNCH2(true, 1, 2); else SKINRT_LAUNCH2(false, 1, 2); }
+            else { if (plan.exact) SKINRT_LAUNCH2(true, 2, 2); else SKINRT_LAUNCH2(false, 2, 2); }
         }
+#undef SKINRT_LAUNCH2
         e = hipGetLastError();
         if (e == hipSuccess && cr.fix && !(SKINRT_ABLATE & 32)) {  // what k_skin2 handed over (the count is on the device: fixed grid)
             // one block per (tile, chunk lane).  Lists are uneven (tiles with many pairs hand over most), so there are

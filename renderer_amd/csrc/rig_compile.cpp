@@ -213,7 +213,7 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
     r.lidx.assign((size_t)T * W * TV, 0);
     r.tile_joint_start.assign(T + 1, 0);
     r.tile_lds.assign(T, 1);
-    r.max_tile_joints = r.max_tile_joints_any = 0;
+    r.max_tile_joints = r.max_tile_joints_any = r.max_tile_joints2 = 0;
     r.lds_tiles = 0;
     std::vector<uint32_t> stamp(J ? J : 1, UINT32_MAX), local_of(J ? J : 1, 0), list;
     for (uint32_t t = 0; t < T; ++t) {
@@ -250,6 +250,7 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
         r.lds_tiles += lds ? 1 : 0;
         r.max_tile_joints_any = std::max<uint32_t>(r.max_tile_joints_any, (uint32_t)list.size());
         if (lds) r.max_tile_joints = std::max<uint32_t>(r.max_tile_joints, (uint32_t)list.size());
+        if (r.tile_lds[t] == 2) r.max_tile_joints2 = std::max<uint32_t>(r.max_tile_joints2, (uint32_t)list.size());
         r.tile_joint_start[t + 1] = r.tile_joint_start[t] + (uint32_t)list.size();
         r.tile_joints.insert(r.tile_joints.end(), list.begin(), list.end());
         float* wt = &r.wts[(size_t)t * W * TV];

@@ -39,11 +39,6 @@ struct MorphPair {
 #define SKINRT_RANGE2 80
 #endif
 constexpr uint32_t kSkin2Range = SKINRT_RANGE2;         // instances per block of the self-staging skinning kernel
-#ifndef SKINRT_PAL_LOOK
-#define SKINRT_PAL_LOOK 2
-#endif
-constexpr uint32_t kSkin2PalLook = SKINRT_PAL_LOOK;         // its palette LDS-DMA runs this many instances ahead
-constexpr uint32_t kSkin2PalRing = kSkin2PalLook + 1;
 constexpr uint32_t kMorphWaveFloats = 576;    // one wave's share of a dense pair = one LDS slot
 constexpr uint32_t kMorphDenseMin = 57;       // touched vertices from which a pair is stored dense
                                               // (a sparse region, 64 + 56*9 floats, still fits a slot)
@@ -80,6 +75,7 @@ struct CompiledRig {
     uint32_t tile_kind_count[3] = {0, 0, 0}; // tiles of each kind
     uint32_t max_tile_joints = 0;            // over LDS tiles
     uint32_t max_tile_joints_any = 0;
+    uint32_t max_tile_joints2 = 0;           // over the self-staging kernel's tiles (kind 2): <= 21
     uint32_t lds_tiles = 0;
     // morph: (tile, target) pairs, targets ascending inside a tile
     std::vector<uint32_t> tile_pair_start;  // [T+1]
