@@ -78,6 +78,46 @@ def cpu_baseline(rig, spec, budget_s=12.0):
     return one, many
 
 
+def measured_bandwidth(device: int):
+    """What this box's HBM does on plain streams (report the fraction of the measured
+    device-to-device copy bandwidth next to the nominal peak): a 4 GiB hipMemcpyDtoD (read + write) and
+    a 4 GiB hipMemset (write only), timed with HIP events after the timed region.  Plain HIP through
+    ctypes, on the runtime the library itself uses."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    def ok(rc):
+        if rc != 0:
+            raise RuntimeError(f"HIP error {rc}")
+    n = 4 << 30
+    ok(hip.hipSetDevice(C.c_int(device)))
+    a, b, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    ok(hip.hipMalloc(C.byref(a), C.c_size_t(n)))
+    try:
+        ok(hip.hipMalloc(C.byref(b), C.c_size_t(n)))
+        ok(hip.hipEventCreate(C.byref(e0))); ok(hip.hipEventCreate(C.byref(e1)))
+        out = {}
+        copy = lambda: ok(hip.hipMemcpyAsync(b, a, C.c_size_t(n), C.c_int(3), None))   # hipMemcpyDeviceToDevice
+        fill = lambda: ok(hip.hipMemsetAsync(a, C.c_int(1), C.c_size_t(n), None))
+        for name, fn, moved in (("fill", fill, n), ("d2d_copy", copy, 2 * n)):
+            for _ in range(2):
+                fn()
+            reps = 8
+            ok(hip.hipEventRecord(e0, None))
+            for _ in range(reps):
+                fn()
+            ok(hip.hipEventRecord(e1, None))
+            ok(hip.hipEventSynchronize(e1))
+            ms = C.c_float()
+            ok(hip.hipEventElapsedTime(C.byref(ms), e0, e1))
+            out[name] = moved * reps / (ms.value * 1e-3) / 1e9
+        return out
+    finally:
+        hip.hipFree(a)
+        if b: hip.hipFree(b)
+        if e0: hip.hipEventDestroy(e0)
+        if e1: hip.hipEventDestroy(e1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +234,12 @@ def main():
             "rig_compile": {"tiles": info.tile_count, "max_tile_joints": info.max_tile_joints,
                             "lds_tiles": info.lds_tiles, "morph_entries": int(info.morph_entries)},
         }
+        try:
+            bw = measured_bandwidth(local_rank)
+            out["roofline"]["measured_GBps"] = {"d2d_copy_read_plus_write": bw["d2d_copy"], "fill_write_only": bw["fill"]}
+            out["roofline"]["frac_of_measured_copy"] = (achieved / 1e9) / bw["d2d_copy"]
+        except Exception as e:  # a reported extra, never a reason to lose the bench line
+            out["roofline"]["measured_GBps"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and n_gpus == 1:
             one, many = cpu_baseline(rig_data, spec)
             out["cpu_baseline"] = one
