@@ -58,7 +58,10 @@ size_t dims_items(const std::string& t) {
 // load_accessor (loader/gltf/mod.rs:240-295)
 std::vector<uint8_t> load_accessor(const Doc& d, const Accessor& a) {
     const json::Value& j = *a.j;
-    if (!j.has("bufferView")) return std::vector<uint8_t>(a.count, 0);  // `count` zero bytes, as the reference
+    if (!j.has("bufferView")) {  // `count` zero bytes, as the reference
+        if (a.count > ((size_t)1 << 32)) fail(SKINRT_E_RANGE, "accessor count too large");
+        return std::vector<uint8_t>(a.count, 0);
+    }
     const size_t num_size = (a.data_type == I8 || a.data_type == U8) ? 1 : (a.data_type == I16 || a.data_type == U16) ? 2 : 4;
     const size_t item_length = num_size * dims_items(a.dims);
     const json::Value& view = d.root["bufferViews"][(size_t)j["bufferView"].as_u64()];
@@ -66,12 +69,15 @@ std::vector<uint8_t> load_accessor(const Doc& d, const Accessor& a) {
     const size_t bi = (size_t)view["buffer"].as_u64();
     if (bi >= d.buffers.size()) fail(SKINRT_E_RANGE, "buffer index out of range");
     const std::vector<uint8_t>& buffer = d.buffers[bi];
-    const size_t offset = (size_t)j["byteOffset"].as_u64() + (size_t)view["byteOffset"].as_u64();
+    const char* past = "accessor reads past its buffer (reference: assert, loader/gltf/mod.rs:272)";
+    const uint64_t off_a = j["byteOffset"].as_u64(), off_v = view["byteOffset"].as_u64();
+    if (off_a > buffer.size() || off_v > buffer.size() || off_a + off_v > buffer.size()) fail(SKINRT_E_RANGE, past);
+    const size_t offset = (size_t)(off_a + off_v);
     const size_t stride = view.has("byteStride") ? (size_t)view["byteStride"].as_u64() : item_length;
     if (stride < item_length) fail(SKINRT_E_INVALID, "bufferView byteStride smaller than the element");
-    const size_t interval = stride - item_length;
-    const size_t full_length = a.count * (item_length + interval);
-    if (offset + full_length > buffer.size()) fail(SKINRT_E_RANGE, "accessor reads past its buffer (reference: assert, loader/gltf/mod.rs:272)");
+    // the reference checks offset + count * stride (a whole stride after the last element too); same
+    // condition, written so that a hostile count or stride cannot wrap it
+    if (a.count != 0 && a.count > (buffer.size() - offset) / stride) fail(SKINRT_E_RANGE, past);
     std::vector<uint8_t> out;
     out.reserve(a.count * item_length);
     for (size_t k = 0; k < a.count; ++k) {
@@ -85,14 +91,14 @@ std::vector<float> load_accessor_f32(const Doc& d, const Accessor& a) {
     if (a.data_type != F32) fail(SKINRT_E_INVALID, "accessor must be FLOAT (reference: assert_eq, loader/gltf/mod.rs:299)");
     const std::vector<uint8_t> raw = load_accessor(d, a);
     std::vector<float> out(raw.size() / 4);
-    std::memcpy(out.data(), raw.data(), out.size() * 4);  // little-endian host
+    if (!out.empty()) std::memcpy(out.data(), raw.data(), out.size() * 4);  // little-endian host
     return out;
 }
 template <class T>
 std::vector<T> load_accessor_uint(const Doc& d, const Accessor& a) {
     const std::vector<uint8_t> raw = load_accessor(d, a);
     std::vector<T> out(raw.size() / sizeof(T));
-    std::memcpy(out.data(), raw.data(), out.size() * sizeof(T));
+    if (!out.empty()) std::memcpy(out.data(), raw.data(), out.size() * sizeof(T));
     return out;
 }
 // load_accessor_normalized (:362-370)
@@ -301,10 +307,18 @@ struct Loader {
         return skin;
     }
 
+    // The reference recurses over `children` without any check (load_node, :1168-1207): a node that
+    // is its own ancestor overflows its stack.  Here a cycle, an absurd depth, or a graph that
+    // re-visits nodes until the walk explodes is an error.
+    std::vector<uint8_t> on_path;
+    size_t visited = 0;
     NodeAsset load_node(uint64_t index, int depth) {
-        if (depth > 4096) fail(SKINRT_E_INVALID, "node hierarchy too deep or cyclic");
         const json::Value& n = d.root["nodes"][(size_t)index];
         if (!n.is_object()) fail(SKINRT_E_RANGE, "node index out of range");
+        if (on_path.size() < d.root["nodes"].size()) on_path.assign(d.root["nodes"].size(), 0);
+        if (on_path[(size_t)index]) fail(SKINRT_E_INVALID, "node hierarchy has a cycle");
+        if (depth > 16384 || ++visited > 4 * on_path.size() + 1024) fail(SKINRT_E_INVALID, "node hierarchy too deep or nodes shared between parents");
+        struct Mark { uint8_t& f; explicit Mark(uint8_t& x) : f(x) { f = 1; } ~Mark() { f = 0; } } mark(on_path[(size_t)index]);
         NodeAsset out;
         out.id = node_id(index);
         if (n["name"].is_string()) out.name = n["name"].str;
@@ -473,7 +487,7 @@ int load_glb_from_buffer_with_id(const uint8_t* buffer, size_t size, const Bundl
             if (jb["byteLength"].as_u64() > bin.size()) fail(SKINRT_E_RANGE, "buffer byteLength exceeds the BIN chunk");
             d.buffers.push_back(bin);
         }
-        Loader L{d, {}};
+        Loader L{d, {}, {}, 0};
         for (const json::Value& a : d.root["animations"].arr) animations.push_back(L.load_animation(a));
         for (const json::Value& s : d.root["scenes"].arr) {
             SceneAsset scene;

@@ -43,7 +43,11 @@ struct Value {
     size_t size() const { return type == Type::Array ? arr.size() : (type == Type::Object ? obj.size() : 0); }
     bool has(const std::string& key) const { return !(*this)[key].is_null(); }
     // numbers as indices / counts
-    uint64_t as_u64(uint64_t fallback = 0) const { return type == Type::Number && num >= 0 ? (uint64_t)num : fallback; }
+    // saturating: a number at or beyond 2^64 (or NaN) must not reach the float -> integer conversion, which is undefined there
+    uint64_t as_u64(uint64_t fallback = 0) const {
+        if (type != Type::Number || !(num >= 0)) return fallback;
+        return num >= 18446744073709551615.0 ? UINT64_MAX : (uint64_t)num;
+    }
     double as_double(double fallback = 0) const { return type == Type::Number ? num : fallback; }
 };
 

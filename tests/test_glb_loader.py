@@ -143,6 +143,57 @@ def test_errors_where_the_reference_panics():
     _expect(_edit(glb, lambda d: d["animations"][0]["channels"][0]["target"].update(node=10 ** 6)), abi.E_RANGE, "unknown node")
 
 
+def test_hostile_files_are_rejected_not_followed():
+    """Where the reference would overflow its stack or wrap an index computation, the loader returns an
+    error (found with tools/fuzz/run.sh: loader + flattener + rig compiler under ASan/UBSan)."""
+    spec = synth.tiny_spec(seed=58)
+    rig = synth.make_rig(spec)
+    glb, _ = write_glb(rig, seed=6)
+    # a node that lists itself as a child: load_node (loader/gltf/mod.rs:1168-1207) recurses forever
+    _expect(_edit(glb, lambda d: d["nodes"][d["scenes"][0]["nodes"][0]].update(children=[d["scenes"][0]["nodes"][0]])),
+            abi.E_INVALID, "cycle")
+    # count * stride wraps 64 bits: the bounds check must not be fooled
+    def wrap(d):
+        acc = d["accessors"][d["meshes"][0]["primitives"][0]["attributes"]["POSITION"]]
+        acc["count"] = 2 ** 61
+        d["bufferViews"][acc["bufferView"]]["byteStride"] = 16
+    _expect(_edit(glb, wrap), abi.E_RANGE, "past its buffer")
+    _expect(_edit(glb, lambda d: d["accessors"][0].update(byteOffset=2 ** 64 - 8)), abi.E_RANGE, "past its buffer")
+    # an accessor without bufferView and an absurd count
+    def huge(d):
+        acc = d["accessors"][d["meshes"][0]["primitives"][0]["attributes"]["NORMAL"]]
+        acc.pop("bufferView"); acc["count"] = 2 ** 40
+    _expect(_edit(glb, huge), abi.E_RANGE, "too large")
+
+
+def test_mutated_files_never_crash_the_loader():
+    """A light version of tools/fuzz/run.sh without the sanitizers: every mutated file loads or is
+    rejected with an error code."""
+    spec = synth.tiny_spec(seed=59, targets=2)
+    glb, _ = write_glb(synth.make_rig(spec), seed=8)
+    rng = np.random.default_rng(4)
+    jl = struct.unpack_from("<I", glb, 12)[0]
+    outcomes = [0, 0]
+    for _ in range(300):
+        m = bytearray(glb)
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            digits = [k for k in range(20, 20 + jl) if 48 <= m[k] <= 57]
+            for k in rng.choice(digits, size=2):
+                m[int(k)] = 48 + int(rng.integers(0, 10))
+        else:
+            m = m[:int(rng.integers(0, len(m)))]
+        try:
+            hostlib.load_glb(bytes(m))
+            outcomes[0] += 1
+        except hostlib.HostError:
+            outcomes[1] += 1
+    assert outcomes[0] > 0 and outcomes[1] > 0, outcomes
+
+
 def test_accessor_without_buffer_view_is_count_zero_bytes():
     # the reference yields `count` zero BYTES (not count x item size): a VEC3 float accessor of count 12
     # becomes 12 bytes = one zero vertex (loader/gltf/mod.rs:241-245)
