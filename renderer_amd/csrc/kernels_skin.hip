@@ -774,6 +774,9 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     if (plan.aabb)
         for (uint32_t c = tid; c < kSkin2Range * 6; c += kSkin2Threads) bb_s[c] = (c % 6 < 3) ? __builtin_inff() : -__builtin_inff();
     __syncthreads();
+    // pairs that move at least one of THIS wave's 64 vertices (bit q, first 32 pairs): the others are
+    // neither requested nor applied by this wave (their deltas here are all zero)
+    const uint32_t my_pairs = (uint32_t)__ballot(lane < min(np, 32u) && ((pairs_s[min(lane, np ? np - 1 : 0u)].wave_mask >> wave) & 1u));
     // active-pair mask of instance-in-range `tid` (bit min(q, 31) = pair q has a non-zero weight).
     // This kernel morphs from its two LDS slots only: an instance with 1 or 2 active pairs, both
     // dense.  Every other non-idle (tile, instance) — 3+ active pairs, a compacted pair, a tile with
@@ -945,7 +948,9 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         const uint32_t ns = min(hx & 0xffu, kMorphSlots);
         const uint32_t lane_bytes = lane * 16;
         for (uint32_t a = 0; a < ns; ++a) {
-            const MorphPair mp = pairs_s[(hx >> (16 + 8 * a)) & 0xffu];
+            const uint32_t q = (hx >> (16 + 8 * a)) & 0xffu;
+            if (!((my_pairs >> q) & 1u)) continue;
+            const MorphPair mp = pairs_s[q];
             const uint32_t doff = __builtin_amdgcn_readfirstlane(mp.data_off);
             const bool dense = __builtin_amdgcn_readfirstlane((uint32_t)mp.dense) != 0;
             const uint32_t n4 = dense ? kMorphWaveFloats / 4 : (__builtin_amdgcn_readfirstlane(mp.floats) + 3) / 4;
@@ -999,8 +1004,8 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         // (3) morph (a13): p = p0 + sum_m w_m * delta_m, targets ascending
         float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
         if (na) {
-            morph_pair<EXACT>(my_slots, true, tid, mw1, p, n, t);
-            if (na >= 2) morph_pair<EXACT>(my_slots + kMorphWaveFloats, true, tid, mw2, p, n, t);
+            if ((my_pairs >> ((hx >> 16) & 0xffu)) & 1u) morph_pair<EXACT>(my_slots, true, tid, mw1, p, n, t);
+            if (na >= 2 && ((my_pairs >> (hx >> 24)) & 1u)) morph_pair<EXACT>(my_slots + kMorphWaveFloats, true, tid, mw2, p, n, t);
         }
         // (4) position
         float op[3];
@@ -1154,13 +1159,14 @@ __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdD
                 const uint32_t q = (uint32_t)__builtin_ctzll(act);
                 const float mw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mwq), q));
                 const MorphPair mp = pairs_l[q];
+                if (!((mp.wave_mask >> wave) & 1u)) continue;  // nothing of this wave's 64 vertices moves: adds exactly 0
                 const bool dense = mp.dense != 0;
                 morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
             }
             for (uint32_t q = pbeg + 64; q < pend; ++q) {
                 const MorphPair mp = rig.pairs[q];
                 const float mw = mwg[mp.target];
-                if (mw == 0.0f) continue;  // wave-uniform; a zero weight adds exactly 0
+                if (mw == 0.0f || !((mp.wave_mask >> wave) & 1u)) continue;  // wave-uniform; adds exactly 0
                 const bool dense = mp.dense != 0;
                 morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
             }

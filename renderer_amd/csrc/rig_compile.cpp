@@ -343,12 +343,17 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
                     for (int e = 0; e < 9; ++e) at(pt.lv[k], e) = pt.dl[k * 9 + e];
                 for (uint32_t l = nvalid; l < TV; ++l)  // padded lanes mirror lane 0
                     for (int e = 0; e < 9; ++e) at(l, e) = at(0, e);
+                for (uint32_t l = 0; l < TV; ++l)
+                    for (int e = 0; e < 9; ++e)
+                        if (at(l, e) != 0.0f) mp.wave_mask |= 1u << (l / 64);
             } else {
                 mp.floats = (TV / 4 + (uint32_t)pt.dl.size() + 3) & ~3u;
                 r.mblock.resize(r.mblock.size() + mp.floats, 0.0f);
                 uint8_t* map = reinterpret_cast<uint8_t*>(&r.mblock[mp.data_off]);
                 for (size_t k = 0; k < pt.lv.size(); ++k) map[pt.lv[k]] = (uint8_t)(k + 1);
                 for (uint32_t l = nvalid; l < TV; ++l) map[l] = map[0];
+                for (uint32_t l = 0; l < TV; ++l)
+                    if (map[l]) mp.wave_mask |= 1u << (l / 64);
                 std::memcpy(&r.mblock[mp.data_off + TV / 4], pt.dl.data(), pt.dl.size() * 4);
             }
             REQUIRE(r.mblock.size() < (1ull << 32), SKINRT_E_INVALID, "morph delta pool exceeds 2^32 floats");

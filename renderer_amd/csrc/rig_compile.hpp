@@ -33,7 +33,7 @@ struct MorphPair {
     uint32_t floats;    // size of the region in floats (sparse: <= kMorphWaveFloats)
     uint16_t target;
     uint16_t dense;
-    uint32_t reserved;
+    uint32_t wave_mask;  // bit w: some vertex of wave w (lanes 64w .. 64w+63) has a non-zero delta; other waves skip the pair
 };
 #ifndef SKINRT_RANGE2
 #define SKINRT_RANGE2 80
