@@ -136,6 +136,31 @@ def test_morph_schedules(oracle32, targets, frac, mode, zero, exact):
     _check_all(got, ref, exact_skin=bool(exact), tag="morph:")
 
 
+def test_stages_run_separately_give_the_same_frame(oracle32):
+    """skinrt_evaluate takes a stage mask: pose only (the palette-only drop-in for SkinUniformBuffer::update),
+    then skinning without bounds, then everything — each must leave exactly what one STAGE_ALL call does."""
+    spec = synth.scaled(synth.CONFIGS["c3"], verts=1500, targets=6, keys=5)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=200)
+    ref = run_oracle(oracle32, rig, crowd)
+    whole = run_gpu(rig, crowd, exact_arithmetic=1)
+    _check_all(whole, ref, exact_skin=True, tag="all:")
+    with api.Context(exact_arithmetic=1) as ctx:
+        r = api.Rig(ctx, rig)
+        c = api.Crowd(ctx, r, 200)
+        c.set_clocks(crowd.tau, crowd.clip_id)
+        c.set_morph_weights(crowd.morph_weights)
+        c.evaluate(abi.STAGE_POSE, sync=True)
+        assert_equal(c.palette(), whole["palette"], "pose only: palette")
+        assert_equal(c.keyframe_index(), whole["key_index"], "pose only: key_index")
+        c.evaluate(abi.STAGE_SKIN, sync=True)           # no bounds: the kernels skip their bounds cells
+        for k, get in (("position", c.positions), ("normal", c.normals), ("tangent", c.tangents)):
+            assert_equal(get().view(np.uint32), whole[k].view(np.uint32), "skin only: " + k)
+        c.evaluate(abi.STAGE_SKIN | abi.STAGE_AABB, sync=True)
+        assert_equal(c.aabbs().view(np.uint32), whole["aabb"].view(np.uint32), "skin + bounds: aabb")
+        c.close(); r.close()
+
+
 def test_scattered_joints_use_global_palette_path(oracle32):
     """Worst-case locality: influences uniform over 300 joints -> tile joint lists exceed the LDS
     cap and the kernel gathers the palette from L2 instead.  Joint gathers must stay exact."""
