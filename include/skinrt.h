@@ -271,6 +271,21 @@ SKINRT_API int skinrt_export_skin_uniform(skinrt_crowd* crowd, uint32_t instance
 SKINRT_API int skinrt_export_interleaved(skinrt_crowd* crowd, uint32_t instance, uint32_t layout,
                               const float* attr, void* dst);
 
+/* ---- load-time geometry ------------------------------------------------ */
+/* calculate_tangent (renderer-asset/src/tangent.rs:15-58) on the device: per-vertex sum of the unit
+ * face normals normalize((p2 - p1) x (p0 - p1)) of the triangles that touch the vertex, added in the
+ * reference's order (triangles ascending, corners 0,1,2), then normalised — bit-equal to the
+ * sequential loop, not an atomic scatter-add.  The reference calls it for primitives without TANGENT
+ * (loader/gltf/mod.rs:1086-1088; its result also stands in for a missing NORMAL, :1089) and for morph
+ * targets without one (:911-916, on the delta positions).
+ * mode: PrimitiveAssetMode ordinal (0 Points, 1 LineStrip, 2 LineList, 3 TriangleStrip, 4 TriangleList);
+ * 3 is SKINRT_E_INVALID (todo!() in the reference, tangent.rs:27); 0-2 have no faces, every vertex
+ * normalises a zero sum (NaN, as the reference).  positions: host [V][3]; indices: host
+ * [index_count] or NULL (then vertices 3f, 3f+1, 3f+2 form triangle f); an index >= V is
+ * SKINRT_E_INVALID (reference: panic).  out: host [V][3].  out_device_ms (may be NULL): time of the
+ * kernels alone (HIP events), without the transfers. */
+SKINRT_API int skinrt_calculate_tangent(skinrt_ctx* ctx, uint32_t mode, const float* positions, uint32_t vertex_count,
+                             const uint32_t* indices, uint32_t index_count, float* out, float* out_device_ms);
 
 #ifdef __cplusplus
 }

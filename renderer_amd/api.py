@@ -32,7 +32,7 @@ EXPORTS = [
     "skinrt_evaluate", "skinrt_synchronize", "skinrt_last_stage_ms", "skinrt_get_stream",
     "skinrt_get_positions", "skinrt_get_normals", "skinrt_get_tangents", "skinrt_get_aabbs",
     "skinrt_get_palette", "skinrt_get_world", "skinrt_get_keyframe_index", "skinrt_download",
-    "skinrt_export_skin_uniform", "skinrt_export_interleaved",
+    "skinrt_export_skin_uniform", "skinrt_export_interleaved", "skinrt_calculate_tangent",
 ]
 
 
@@ -77,6 +77,7 @@ def load_library() -> C.CDLL:
         "skinrt_download": [vp, vp, vp, C.c_uint64],
         "skinrt_export_skin_uniform": [vp, C.c_uint32, vp],
         "skinrt_export_interleaved": [vp, C.c_uint32, C.c_uint32, vp, vp],
+        "skinrt_calculate_tangent": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(C.c_float)],
     }
     for g in ("positions", "normals", "tangents", "aabbs", "palette", "world", "keyframe_index"):
         sigs[f"skinrt_get_{g}"] = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
@@ -136,6 +137,18 @@ class Context:
         out = np.empty(count, dtype=dtype)
         _check(self.lib.skinrt_download(self.handle, C.c_void_p(dev_ptr), out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
+
+    def calculate_tangent(self, mode: int, positions, indices=None, with_ms: bool = False):
+        """calculate_tangent (renderer-asset/src/tangent.rs:15-58) on the device; returns [V][3] float32
+        (and the kernels' time in ms when with_ms)."""
+        p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        idx = None if indices is None else np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        out = np.zeros_like(p)
+        ms = C.c_float(0.0)
+        _check(self.lib.skinrt_calculate_tangent(self.handle, mode, p.ctypes.data_as(C.c_void_p), p.shape[0],
+                                                 None if idx is None else idx.ctypes.data_as(C.c_void_p),
+                                                 0 if idx is None else idx.shape[0], out.ctypes.data_as(C.c_void_p), C.byref(ms)))
+        return (out, float(ms.value)) if with_ms else out
 
     def close(self):
         if self.handle:

@@ -603,4 +603,44 @@ int skinrt_export_interleaved(skinrt_crowd* c, uint32_t instance, uint32_t layou
     return SKINRT_OK;
 }
 
+int skinrt_calculate_tangent(skinrt_ctx* ctx, uint32_t mode, const float* positions, uint32_t vertex_count,
+                             const uint32_t* indices, uint32_t index_count, float* out, float* out_device_ms) {
+    if (!ctx) return fail(SKINRT_E_INVALID, "ctx is NULL");
+    if (mode > 4) return fail(SKINRT_E_INVALID, "mode must be a PrimitiveAssetMode ordinal (0..4)");
+    if (mode == 3) return fail(SKINRT_E_INVALID, "TriangleStrip: todo!() in the reference (tangent.rs:27)");
+    if (vertex_count == 0) return SKINRT_OK;
+    if (!positions || !out) return fail(SKINRT_E_INVALID, "skinrt_calculate_tangent: NULL pointer");
+    if (indices == nullptr && index_count != 0) return fail(SKINRT_E_INVALID, "index_count without indices");
+    // only triangle lists have faces; points and lines leave every sum at zero (and normalise to NaN, as the reference)
+    uint32_t corners = 0;
+    if (mode == 4) corners = (indices ? index_count : vertex_count) / 3 * 3;
+    if (indices)
+        for (uint32_t k = 0; k < corners; ++k)
+            if (indices[k] >= vertex_count) return fail(SKINRT_E_INVALID, "vertex index out of range (reference: index panic)");
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    const size_t work_bytes = tangent_work_bytes(vertex_count, corners);
+    DevBuf dpos, didx, dwork, dout;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = dpos.alloc((size_t)vertex_count * 12);
+    if (e == hipSuccess && indices && corners) e = didx.alloc((size_t)corners * 4);
+    if (e == hipSuccess) e = dwork.alloc(work_bytes);
+    if (e == hipSuccess) e = dout.alloc((size_t)vertex_count * 12);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    hipStream_t s = ctx->stream;
+    if (e == hipSuccess) e = hipMemcpyAsync(dpos.p, positions, (size_t)vertex_count * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && didx.p) e = hipMemcpyAsync(didx.p, indices, (size_t)corners * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipEventRecord(e0, s);
+    if (e == hipSuccess) e = launch_tangents(dpos.as<float>(), didx.as<uint32_t>(), vertex_count, corners, dwork.p, work_bytes, dout.as<float>(), s);
+    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, (size_t)vertex_count * 12, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && out_device_ms) e = hipEventElapsedTime(out_device_ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    dpos.release(); didx.release(); dwork.release(); dout.release();
+    if (e != hipSuccess) return fail(SKINRT_E_DEVICE, std::string("skinrt_calculate_tangent: ") + hipGetErrorString(e));
+    return SKINRT_OK;
+}
+
 }  // extern "C"

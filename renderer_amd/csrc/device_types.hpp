@@ -94,6 +94,10 @@ hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t cubic_qui
 // kernels_skin.hip
 hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s);
 hipError_t launch_aabb_reduce(const RigDev& rig, const CrowdDev& cr, hipStream_t s);
+// kernels_geom.hip: calculate_tangent on the device (load time)
+size_t tangent_work_bytes(uint32_t vertices, uint32_t corners);
+hipError_t launch_tangents(const float* pos, const uint32_t* indices, uint32_t vertices, uint32_t corners, void* work, size_t work_bytes,
+                           float* out, hipStream_t s);
 hipError_t launch_fill_morph_weights(float* mw, const float* defaults, uint32_t I, uint32_t M, hipStream_t s);
 
 }  // namespace skinrt

@@ -1,0 +1,108 @@
+// kernels_geom.hip — load-time geometry next to the path: the reference's
+// calculate_tangent (renderer-asset/src/tangent.rs:15-58) on the device.
+//
+// The reference walks the triangles in order and ADDS each unit face normal to its three vertices,
+// then normalises per vertex.  Floating-point addition is not associative, so a scatter-add with
+// atomics would give run-to-run different bits.  Here the sum is turned into a gather with the
+// reference's order: corners (3 per triangle, numbered 3f + k) are bucketed per vertex
+// (count -> exclusive scan -> fill), each vertex sorts its few corner ids ascending — which is the
+// order in which the sequential loop reached it — and adds the face normals in that order.  The
+// result is bit-equal to the sequential loop.  Compiled with -ffp-contract=off (glam's scalar Vec3
+// does separate multiplies and adds).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "device_types.hpp"
+
+namespace skinrt {
+
+namespace {
+
+__device__ __forceinline__ uint32_t corner_vertex(const uint32_t* __restrict__ indices, uint32_t c) { return indices ? indices[c] : c; }
+
+// unit normal of face f: normalize((p2 - p1) x (p0 - p1)), glam operation order (tangent.rs:32-41)
+__global__ __launch_bounds__(256) void k_face_normals(const float* __restrict__ pos, const uint32_t* __restrict__ indices,
+                                                      uint32_t faces, float* __restrict__ fn) {
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= faces) return;
+    const uint32_t i0 = corner_vertex(indices, 3 * f), i1 = corner_vertex(indices, 3 * f + 1), i2 = corner_vertex(indices, 3 * f + 2);
+    const float* p0 = pos + (size_t)i0 * 3; const float* p1 = pos + (size_t)i1 * 3; const float* p2 = pos + (size_t)i2 * 3;
+    const float a[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    const float b[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
+    const float c[3] = {a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1]};
+    const float r = 1.0f / sqrtf((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
+    fn[(size_t)f * 3 + 0] = c[0] * r; fn[(size_t)f * 3 + 1] = c[1] * r; fn[(size_t)f * 3 + 2] = c[2] * r;
+}
+
+__global__ __launch_bounds__(256) void k_corner_count(const uint32_t* __restrict__ indices, uint32_t corners, uint32_t* __restrict__ cnt) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c < corners) atomicAdd(&cnt[corner_vertex(indices, c)], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_corner_fill(const uint32_t* __restrict__ indices, uint32_t corners, const uint32_t* __restrict__ start,
+                                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ adj) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= corners) return;
+    const uint32_t v = corner_vertex(indices, c);
+    adj[start[v] + atomicAdd(&cursor[v], 1u)] = c;
+}
+
+// one thread per vertex: its corners ascending (insertion sort in place: a vertex has a handful),
+// face normals added in that order, then v * (1 / sqrt(dot(v, v))) (tangent.rs:52-56)
+__global__ __launch_bounds__(256) void k_vertex_sum(uint32_t vertices, const uint32_t* __restrict__ start, uint32_t* __restrict__ adj,
+                                                    const float* __restrict__ fn, float* __restrict__ out) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= vertices) return;
+    const uint32_t b = start[v], e = start[v + 1];
+    for (uint32_t i = b + 1; i < e; ++i) {
+        const uint32_t key = adj[i];
+        uint32_t j = i;
+        for (; j > b && adj[j - 1] > key; --j) adj[j] = adj[j - 1];
+        adj[j] = key;
+    }
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    for (uint32_t i = b; i < e; ++i) {
+        const float* n = fn + (size_t)(adj[i] / 3) * 3;
+        s0 += n[0]; s1 += n[1]; s2 += n[2];
+    }
+    const float r = 1.0f / sqrtf((s0 * s0 + s1 * s1) + s2 * s2);
+    out[(size_t)v * 3 + 0] = s0 * r; out[(size_t)v * 3 + 1] = s1 * r; out[(size_t)v * 3 + 2] = s2 * r;
+}
+
+}  // namespace
+
+// pos: [V][3] device; indices: [corners] device or nullptr (then corner c is vertex c); corners = 3 * faces;
+// work: device scratch of tangent_work_bytes(V, corners); out: [V][3] device
+size_t tangent_work_bytes(uint32_t vertices, uint32_t corners) {
+    size_t scan = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)vertices + 1);
+    return ((size_t)(vertices + 1) * 3 + corners) * 4 + (size_t)corners * 4 /* face normals: corners/3*3 floats */ + scan + 256;
+}
+
+hipError_t launch_tangents(const float* pos, const uint32_t* indices, uint32_t vertices, uint32_t corners, void* work, size_t work_bytes,
+                           float* out, hipStream_t s) {
+    if (vertices == 0) return hipSuccess;
+    uint32_t* cnt = static_cast<uint32_t*>(work);           // [V+1] corner counts, then scanned into start
+    uint32_t* start = cnt + (vertices + 1);                 // [V+1]
+    uint32_t* cursor = start + (vertices + 1);              // [V+1]
+    uint32_t* adj = cursor + (vertices + 1);                // [corners]
+    float* fn = reinterpret_cast<float*>(adj + corners);    // [faces][3]
+    void* scan_tmp = fn + corners;
+    const size_t used = (size_t)(reinterpret_cast<char*>(scan_tmp) - static_cast<char*>(work));
+    if (used > work_bytes) return hipErrorInvalidValue;
+    size_t scan_bytes = work_bytes - used;
+    const uint32_t faces = corners / 3;
+    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)(vertices + 1) * 3 * 4, s);  // cnt, start, cursor
+    if (e != hipSuccess) return e;
+    if (corners) {
+        hipLaunchKernelGGL(k_face_normals, dim3((faces + 255) / 256), dim3(256), 0, s, pos, indices, faces, fn);
+        hipLaunchKernelGGL(k_corner_count, dim3((corners + 255) / 256), dim3(256), 0, s, indices, corners, cnt);
+    }
+    e = hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cnt, start, (int)vertices + 1, s);
+    if (e != hipSuccess) return e;
+    if (corners) hipLaunchKernelGGL(k_corner_fill, dim3((corners + 255) / 256), dim3(256), 0, s, indices, corners, start, cursor, adj);
+    hipLaunchKernelGGL(k_vertex_sum, dim3((vertices + 255) / 256), dim3(256), 0, s, vertices, start, adj, fn, out);
+    return hipGetLastError();
+}
+
+}  // namespace skinrt
