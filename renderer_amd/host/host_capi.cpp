@@ -7,11 +7,13 @@
 
 #include "flatten.hpp"
 #include "gltf_loader.hpp"
+#include "pmx_loader.hpp"
 
 using namespace skinrt_host;
 
 struct skinrt_host_rig {
     FlatRig flat;
+    PmxInfo pmx;  // filled by skinrt_host_load_pmx
 };
 
 namespace {
@@ -47,6 +49,40 @@ int skinrt_host_load_glb(const uint8_t* data, size_t size, int scene, skinrt_hos
     } catch (const std::bad_alloc&) {
         return fail(SKINRT_E_NOMEM, "out of memory");
     }
+}
+
+int skinrt_host_load_pmx(const uint8_t* data, size_t size, skinrt_host_rig** out) {
+    if (!out) return fail(SKINRT_E_INVALID, "out is NULL");
+    *out = nullptr;
+    try {
+        auto* rig = new skinrt_host_rig();
+        std::string err;
+        BundleIndex id{};
+        const int rc = load_pmx_from_buffer(data, size, id, rig->flat, rig->pmx, err);
+        if (rc != SKINRT_OK) {
+            delete rig;
+            return fail(rc, err);
+        }
+        *out = rig;
+        return SKINRT_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(SKINRT_E_NOMEM, "out of memory");
+    }
+}
+
+const uint32_t* skinrt_host_rig_pmx_indices(const skinrt_host_rig* rig, uint32_t* count) {
+    if (count) *count = rig ? (uint32_t)rig->pmx.indices.size() : 0;
+    return (rig && !rig->pmx.indices.empty()) ? rig->pmx.indices.data() : nullptr;
+}
+
+void skinrt_host_rig_pmx_counts(const skinrt_host_rig* rig, uint32_t out[10]) {
+    for (int k = 0; k < 10; ++k) out[k] = 0;
+    if (!rig) return;
+    const PmxInfo& p = rig->pmx;
+    out[0] = p.vertices; out[1] = p.triangles; out[2] = p.materials; out[3] = p.bones; out[4] = p.morphs; out[5] = p.vertex_morphs;
+    // out[6..9]: BDEF1, BDEF2 + SDEF, BDEF4 + QDEF, SDEF + QDEF (the ones blended linearly as an approximation)
+    out[6] = p.deform_count[0]; out[7] = p.deform_count[1] + p.deform_count[3]; out[8] = p.deform_count[2] + p.deform_count[4];
+    out[9] = p.deform_count[3] + p.deform_count[4];
 }
 
 const skinrt_rig_desc* skinrt_host_rig_desc(skinrt_host_rig* rig) { return rig ? rig->flat.desc() : nullptr; }

@@ -17,6 +17,15 @@ typedef struct skinrt_host_rig skinrt_host_rig;
 /* load_glb_from_buffer (renderer-asset/src/loader/gltf/mod.rs:1358-1381) followed by the flatten
  * walk (flatten.hpp).  scene = -1: all scenes.  Returns SKINRT_OK or SKINRT_E_*. */
 SKINRT_API int skinrt_host_load_glb(const uint8_t* data, size_t size, int scene, skinrt_host_rig** out);
+/* PMX 2.0 model -> flat rig (pmx_loader.hpp: the reference parses bones, weights and morphs and drops
+ * them, loader/pmx/mod.rs:200-262; the mapping onto the rig is build-defined).  Node n of the rig is
+ * PMX bone skinrt_host_rig_node_gltf_index(rig, n). */
+SKINRT_API int skinrt_host_load_pmx(const uint8_t* data, size_t size, skinrt_host_rig** out);
+/* the model's surface list (3 vertex indices per triangle); NULL / 0 for rigs that are not PMX */
+SKINRT_API const uint32_t* skinrt_host_rig_pmx_indices(const skinrt_host_rig* rig, uint32_t* count);
+/* vertices, triangles, materials, bones, morphs, vertex morphs, then vertices by deform class:
+ * BDEF1, BDEF2+SDEF, BDEF4+QDEF, SDEF+QDEF */
+SKINRT_API void skinrt_host_rig_pmx_counts(const skinrt_host_rig* rig, uint32_t out[10]);
 /* descriptor for skinrt_upload_rig / skinrt_validate_rig; valid until the rig is freed */
 SKINRT_API const skinrt_rig_desc* skinrt_host_rig_desc(skinrt_host_rig* rig);
 /* glTF node index of flat node n (the flattening order under test) */

@@ -32,6 +32,12 @@ def load_library() -> C.CDLL:
         lib = C.CDLL(_PATH)
         lib.skinrt_host_load_glb.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         lib.skinrt_host_load_glb.restype = C.c_int
+        lib.skinrt_host_load_pmx.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        lib.skinrt_host_load_pmx.restype = C.c_int
+        lib.skinrt_host_rig_pmx_indices.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        lib.skinrt_host_rig_pmx_indices.restype = C.POINTER(C.c_uint32)
+        lib.skinrt_host_rig_pmx_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 10)]
+        lib.skinrt_host_rig_pmx_counts.restype = None
         lib.skinrt_host_rig_desc.argtypes = [C.c_void_p]
         lib.skinrt_host_rig_desc.restype = C.POINTER(RigDesc)
         lib.skinrt_host_rig_node_gltf_index.argtypes = [C.c_void_p, C.c_uint32]
@@ -116,3 +122,27 @@ def calculate_tangent(mode: int, positions, indices=None) -> np.ndarray:
     if rc != 0:
         raise HostError(rc, lib.skinrt_host_last_error().decode("utf-8", "replace"))
     return out
+
+
+def load_pmx(data: bytes):
+    """PMX 2.0 model -> (rig, PMX bone index per flat node, surface indices, counts dict).  See
+    renderer_amd/host/pmx_loader.hpp for the (build-defined) mapping."""
+    lib = load_library()
+    h = C.c_void_p()
+    rc = lib.skinrt_host_load_pmx(data, len(data), C.byref(h))
+    if rc != 0:
+        raise HostError(rc, lib.skinrt_host_last_error().decode("utf-8", "replace"))
+    try:
+        d = lib.skinrt_host_rig_desc(h).contents
+        rig = _rig_from_desc(d)
+        rig.name = "pmx"
+        order = np.array([lib.skinrt_host_rig_node_gltf_index(h, k) for k in range(d.node_count)], np.uint32)
+        n = C.c_uint32(0)
+        ip = lib.skinrt_host_rig_pmx_indices(h, C.byref(n))
+        indices = _np(ip, (n.value,), np.uint32)
+        cnt = (C.c_uint32 * 10)()
+        lib.skinrt_host_rig_pmx_counts(h, C.byref(cnt))
+        names = ("vertices", "triangles", "materials", "bones", "morphs", "vertex_morphs", "bdef1", "bdef2", "bdef4", "approximated")
+        return rig, order, indices, dict(zip(names, [int(x) for x in cnt]))
+    finally:
+        lib.skinrt_host_free_rig(h)

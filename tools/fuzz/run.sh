@@ -1,5 +1,5 @@
 #!/bin/bash
-# Host-side robustness run: glb loader + flattener + rig compiler under ASan/UBSan on mutated files.
+# Host-side robustness run: glb and PMX loaders + flattener + rig compiler under ASan/UBSan on mutated files.
 # usage: tools/fuzz/run.sh [iterations]      (CPU only; a few seconds per 10,000 variants)
 set -e
 cd "$(dirname "$0")/../.."
@@ -13,8 +13,16 @@ for name, spec in (("a", synth.tiny_spec(seed=51, matrix_nodes=2)),
                    ("b", synth.tiny_spec(seed=52, sets=2, target_mode="sparse", target_frac=0.3, targets=4))):
     glb, _ = write_glb(synth.make_rig(spec), seed=7)
     open("$B/" + name + ".glb", "wb").write(glb)
+from tests.pmx_writer import write_pmx
+from tests.test_pmx_loader import model
+pos, nrm, idx, bones, deforms, morphs, _, _ = model()
+open("$B/a.pmx", "wb").write(write_pmx(pos, nrm, idx, bones, deforms, morphs, materials=[300, 300],
+                                       other_morphs=("group", "bone", "uv", "material", "flip", "impulse")))
 PY
 SAN="-fsanitize=address,undefined,float-cast-overflow -fno-sanitize-recover=undefined,float-cast-overflow -fno-omit-frame-pointer"
 g++ -O1 -g -std=c++17 $SAN -ffp-contract=off tools/fuzz/fuzz_glb.cpp renderer_amd/host/host_capi.cpp renderer_amd/host/gltf_loader.cpp \
-    renderer_amd/host/flatten.cpp renderer_amd/csrc/rig_compile.cpp -o $B/fuzz_glb
+    renderer_amd/host/pmx_loader.cpp renderer_amd/host/flatten.cpp renderer_amd/csrc/rig_compile.cpp -o $B/fuzz_glb
+g++ -O1 -g -std=c++17 $SAN -ffp-contract=off tools/fuzz/fuzz_pmx.cpp renderer_amd/host/host_capi.cpp renderer_amd/host/gltf_loader.cpp \
+    renderer_amd/host/pmx_loader.cpp renderer_amd/host/flatten.cpp renderer_amd/csrc/rig_compile.cpp -o $B/fuzz_pmx
 for f in a b; do for seed in 1 2 3; do ASAN_OPTIONS=detect_leaks=1 timeout 900 $B/fuzz_glb $B/$f.glb $IT $seed; done; done
+for seed in 1 2 3; do ASAN_OPTIONS=detect_leaks=1 timeout 900 $B/fuzz_pmx $B/a.pmx $IT $seed; done
