@@ -231,6 +231,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "skin stage = k_skin2 + k_skin_fix (morph + linear-blend skinning + per-tile bounds)", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": skin_ms, "traffic": traffic},
+            "output_placement": crowd.placement,
             "rig_compile": {"tiles": info.tile_count, "max_tile_joints": info.max_tile_joints,
                             "lds_tiles": info.lds_tiles, "morph_entries": int(info.morph_entries)},
         }

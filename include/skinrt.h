@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SKINRT_ABI_VERSION 1
+#define SKINRT_ABI_VERSION 2
 #define SKINRT_API __attribute__((visibility("default")))
 
 /* ---- error codes ---------------------------------------------------------------- */
@@ -94,6 +94,14 @@ typedef struct skinrt_config {
     /* 0: choose per tile; 1: only the loader-wave skinning kernel (the self-staging kernel, used
      *    for tiles with at most 21 joints and rigs with at most 2 weight sets, is switched off). */
     uint32_t skin_path;
+    /* Where skinrt_create_crowd puts the position / normal / tangent arrays of a large crowd
+     * (3 arrays >= 1 GiB together).  0: one array per third of the device's physical HBM address
+     * space — on MI355X a write stream confined to one third runs at ~5.4 TB/s, streams spread over
+     * the thirds at ~7 TB/s; the arrays are steered there with transient filler allocations that are
+     * freed before the call returns (up to two thirds of the device's free memory is reserved for
+     * the duration of skinrt_create_crowd), and the result is measured (skinrt_get_output_placement).
+     * 1: three plain hipMalloc calls, no filler, no measurement. */
+    uint32_t output_placement;
 } skinrt_config;
 
 /* ---- flat rig ("loader output", SURVEY.md §8a rows a1,a5-a8,a11,a13) ---------------- */
@@ -182,6 +190,18 @@ typedef struct skinrt_rig_info {
     uint64_t device_bytes;         /* bytes of device memory the rig occupies */
 } skinrt_rig_info;
 
+/* What skinrt_create_crowd did with the output arrays and what it measured (all zero for small crowds
+ * and for output_placement=1). */
+typedef struct skinrt_placement_info {
+    uint32_t strategy;          /* 0: plain allocations, 1: steered with filler allocations */
+    uint32_t reserved;
+    uint64_t filler_bytes;      /* transient reservation during skinrt_create_crowd */
+    float probe_together_ms;    /* the skin stage's store pattern, no arithmetic, on all three arrays */
+    float probe_alone_ms;       /* the same on the position array alone */
+    float spread_gain;          /* 3 * alone / together: ~1.0 = one region, ~1.25-1.3 = spread */
+    float probe_GBps;           /* bytes of the three arrays / probe_together_ms */
+} skinrt_placement_info;
+
 /* ---- lifecycle --------------------------------------------------------------------- */
 
 /* Library/ABI version (SKINRT_ABI_VERSION). No reference counterpart. */
@@ -211,6 +231,9 @@ SKINRT_API int skinrt_get_rig_info(skinrt_rig* rig, skinrt_rig_info* out_info);
  * Replaces one SkinUniformBuffer::new per entity (renderer/uniform/skin.rs:39-57). */
 SKINRT_API int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, skinrt_crowd** out_crowd);
 SKINRT_API int skinrt_destroy_crowd(skinrt_crowd* crowd);
+
+/* Output-array placement chosen and measured at skinrt_create_crowd. No reference counterpart. */
+SKINRT_API int skinrt_get_output_placement(skinrt_crowd* crowd, skinrt_placement_info* out_info);
 
 /* ---- per-frame inputs ----------------------------------------------------------------- */
 

@@ -37,6 +37,19 @@ class Config(C.Structure):
         ("exact_arithmetic", C.c_uint32),
         ("pose_path", C.c_uint32),
         ("skin_path", C.c_uint32),
+        ("output_placement", C.c_uint32),
+    ]
+
+
+class PlacementInfo(C.Structure):
+    _fields_ = [
+        ("strategy", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("filler_bytes", C.c_uint64),
+        ("probe_together_ms", C.c_float),
+        ("probe_alone_ms", C.c_float),
+        ("spread_gain", C.c_float),
+        ("probe_GBps", C.c_float),
     ]
 
 

@@ -19,7 +19,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import abi
-from .abi import Config, RigData, RigDesc, RigInfo
+from .abi import Config, PlacementInfo, RigData, RigDesc, RigInfo
 
 _LIB_PATH = os.environ.get("SKINRT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libskinrt.so")
 _lib = None
@@ -27,7 +27,7 @@ _lib = None
 # every symbol include/skinrt.h declares
 EXPORTS = [
     "skinrt_abi_version", "skinrt_last_error", "skinrt_init", "skinrt_destroy_ctx", "skinrt_upload_rig",
-    "skinrt_validate_rig", "skinrt_destroy_rig", "skinrt_get_rig_info", "skinrt_create_crowd",
+    "skinrt_validate_rig", "skinrt_destroy_rig", "skinrt_get_rig_info", "skinrt_create_crowd", "skinrt_get_output_placement",
     "skinrt_destroy_crowd", "skinrt_set_clocks", "skinrt_set_morph_weights", "skinrt_set_root_transforms",
     "skinrt_evaluate", "skinrt_synchronize", "skinrt_last_stage_ms", "skinrt_get_stream",
     "skinrt_get_positions", "skinrt_get_normals", "skinrt_get_tangents", "skinrt_get_aabbs",
@@ -67,6 +67,7 @@ def load_library() -> C.CDLL:
         "skinrt_get_rig_info": [vp, C.POINTER(RigInfo)],
         "skinrt_create_crowd": [vp, vp, C.c_uint32, C.POINTER(vp)],
         "skinrt_destroy_crowd": [vp],
+        "skinrt_get_output_placement": [vp, C.POINTER(PlacementInfo)],
         "skinrt_set_clocks": [vp, vp, vp],
         "skinrt_set_morph_weights": [vp, vp],
         "skinrt_set_root_transforms": [vp, vp],
@@ -95,7 +96,7 @@ def _check(rc: int):
 
 
 def make_config(device: int = 0, cubic_quirk: int = 1, normalize_outputs: int = 0, reference_limits: int = 0,
-                exact_arithmetic: int = 0, pose_path: int = 0, skin_path: int = 0) -> Config:
+                exact_arithmetic: int = 0, pose_path: int = 0, skin_path: int = 0, output_placement: int = 0) -> Config:
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.device = device
@@ -105,6 +106,7 @@ def make_config(device: int = 0, cubic_quirk: int = 1, normalize_outputs: int = 
     cfg.exact_arithmetic = exact_arithmetic
     cfg.pose_path = pose_path
     cfg.skin_path = skin_path
+    cfg.output_placement = output_placement
     return cfg
 
 
@@ -187,6 +189,15 @@ class Crowd:
         self.ctx, self.rig, self.instances = ctx, rig, int(instances)
         self.handle = C.c_void_p()
         _check(ctx.lib.skinrt_create_crowd(ctx.handle, rig.handle, self.instances, C.byref(self.handle)))
+
+    @property
+    def placement(self) -> dict:
+        """What skinrt_create_crowd did with the output arrays and what it measured."""
+        info = PlacementInfo()
+        _check(self.ctx.lib.skinrt_get_output_placement(self.handle, C.byref(info)))
+        return {"strategy": "steered" if info.strategy else "plain", "filler_GiB": info.filler_bytes / 2 ** 30,
+                "probe_together_ms": info.probe_together_ms, "probe_alone_ms": info.probe_alone_ms,
+                "spread_gain": info.spread_gain, "probe_GBps": info.probe_GBps}
 
     # inputs ------------------------------------------------------------------------------
     def set_clocks(self, tau, clip_id=None):

@@ -74,6 +74,7 @@ struct skinrt_crowd {
     bool has_root = false;
     SkinPlan plan{};
     PosePath pose_path = kPoseWave;
+    skinrt_placement_info place{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t last_mask = 0;
     CrowdDev dev() const {
@@ -210,6 +211,7 @@ int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx) {
     if (config->struct_size != sizeof(skinrt_config)) return fail(SKINRT_E_INVALID, "skinrt_config.struct_size mismatch");
     if (config->pose_path > 2) return fail(SKINRT_E_INVALID, "skinrt_config.pose_path must be 0, 1 or 2");
     if (config->skin_path > 1) return fail(SKINRT_E_INVALID, "skinrt_config.skin_path must be 0 or 1");
+    if (config->output_placement > 1) return fail(SKINRT_E_INVALID, "skinrt_config.output_placement must be 0 or 1");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (config->device < 0 || config->device >= count) return fail(SKINRT_E_DEVICE, "no such HIP device");
@@ -265,7 +267,13 @@ int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig**
         delete r;
         return fail(rc, err);
     }
-    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    {
+        hipError_t se = hipSetDevice(ctx->cfg.device);
+        if (se != hipSuccess) {
+            delete r;
+            return fail(SKINRT_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(se));
+        }
+    }
     const CompiledRig& h = r->host;
     RigDev& d = r->dev;
     d.N = h.N; d.J = h.J; d.V = h.V; d.K = h.K; d.M = h.M; d.clips = h.clips; d.Cmax = h.Cmax;
@@ -287,82 +295,6 @@ int skinrt_get_rig_info(skinrt_rig* rig, skinrt_rig_info* out_info) {
     fill_rig_info(rig->host, rig->device_bytes, out_info);
     return SKINRT_OK;
 }
-
-namespace {
-
-// Where the output arrays land in HBM.  On MI355X the skin stage runs in one of two speed states
-// that differ by 8 % (C3: 3.85 vs 4.15 ms without morph targets) and the state is a property of
-// the hipMalloc'ed position / normal / tangent arrays: it stays for the life of the allocation,
-// does not depend on virtual addresses, offsets or data, and changes when the arrays are
-// allocated again somewhere else (tools/exp_state.py; the cause — presumably how the physical
-// pages map to HBM channels and banks — is not visible from user space).  So a large crowd tries
-// a few allocations at creation: each candidate set is timed with the real skin kernel (palette
-// and morph weights zero; only relative times matter), losers are held until the end so that the
-// next candidate lands on other pages, and the fastest set is kept.  Small crowds and crowds
-// that do not leave room for a second set skip this.  SKINRT_PLACEMENT_TRIALS=<n> caps the number
-// of extra allocations (0 switches the search off; default 5).
-hipError_t tune_output_placement(skinrt_crowd* c) {
-    const size_t set_bytes = c->pos.bytes + c->nrm.bytes + c->tan.bytes;
-    uint32_t trials = 5;
-    if (const char* env = getenv("SKINRT_PLACEMENT_TRIALS")) trials = (uint32_t)strtoul(env, nullptr, 0);
-    if (trials == 0 || set_bytes < ((size_t)1 << 30)) return hipSuccess;
-    hipStream_t s = c->ctx->stream;
-    hipError_t e = hipMemsetAsync(c->palette.p, 0, c->palette.bytes, s);
-    if (e == hipSuccess && c->mw.p) e = hipMemsetAsync(c->mw.p, 0, c->mw.bytes, s);
-    if (e != hipSuccess) return e;
-    SkinPlan p = c->plan;
-    p.aabb = 1;
-    auto time_set = [&](float* ms) -> hipError_t {
-        const CrowdDev cr = c->dev();
-        *ms = 3.0e38f;
-        for (int rep = 0; rep < 5; ++rep) {  // two warm-up runs
-            hipError_t r = hipEventRecord(c->ev[0], s);
-            if (r == hipSuccess) r = launch_skin(c->rig->dev, cr, p, s);
-            if (r == hipSuccess) r = hipEventRecord(c->ev[1], s);
-            if (r == hipSuccess) r = hipEventSynchronize(c->ev[1]);
-            float t = 0.0f;
-            if (r == hipSuccess) r = hipEventElapsedTime(&t, c->ev[0], c->ev[1]);
-            if (r != hipSuccess) return r;
-            if (rep >= 2) *ms = std::min(*ms, t);
-        }
-        return hipSuccess;
-    };
-    struct Set { DevBuf pos, nrm, tan; float ms; };
-    std::vector<Set> held;  // every candidate but the current one
-    float cur_ms = 0.0f, worst = 0.0f;
-    if ((e = time_set(&cur_ms)) != hipSuccess) return e;
-    worst = cur_ms;
-    const bool verbose = getenv("SKINRT_DEBUG_PLACE") != nullptr;
-    if (verbose) fprintf(stderr, "skinrt placement: first set %.3f ms\n", cur_ms);
-    for (uint32_t k = 0; k < trials; ++k) {
-        float best = cur_ms;
-        for (const Set& h : held) best = std::min(best, h.ms);
-        if (best <= 0.90f * worst) break;  // both ends of the range seen: a fast set is in hand
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < set_bytes + set_bytes / 2) break;
-        Set cand{};
-        if (cand.pos.alloc(c->pos.bytes) != hipSuccess || cand.nrm.alloc(c->nrm.bytes) != hipSuccess ||
-            cand.tan.alloc(c->tan.bytes) != hipSuccess) {
-            cand.pos.release(); cand.nrm.release(); cand.tan.release();
-            (void)hipGetLastError();
-            break;
-        }
-        held.push_back(Set{c->pos, c->nrm, c->tan, cur_ms});
-        c->pos = cand.pos; c->nrm = cand.nrm; c->tan = cand.tan;
-        if ((e = time_set(&cur_ms)) != hipSuccess) break;
-        worst = std::max(worst, cur_ms);
-        if (verbose) fprintf(stderr, "skinrt placement: candidate %u %.3f ms\n", k + 1, cur_ms);
-    }
-    // keep the fastest set, free the rest
-    for (Set& h : held)
-        if (e == hipSuccess && h.ms < cur_ms) {
-            std::swap(h.pos, c->pos); std::swap(h.nrm, c->nrm); std::swap(h.tan, c->tan); std::swap(h.ms, cur_ms);
-        }
-    for (Set& h : held) { h.pos.release(); h.nrm.release(); h.tan.release(); }
-    return e;
-}
-
-}  // namespace
 
 int skinrt_destroy_crowd(skinrt_crowd* c) {
     if (!c) return SKINRT_OK;
@@ -395,7 +327,6 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
     struct { DevBuf* b; size_t n; } plan[] = {
         {&c->tau, I * 4}, {&c->clip, I * 4}, {&c->mw, I * h.M * 4}, {&c->root, I * 48},
         {&c->world, I * h.N * 48}, {&c->palette, I * h.J * 96}, {&c->keyidx, I * h.Cmax * 4},
-        {&c->pos, I * h.V * 12}, {&c->nrm, I * h.V * 12}, {&c->tan, I * h.V * 12},
         {&c->aabb_part, I * h.T * 24}, {&c->aabb, I * 24},      // bounds per (instance, tile)
         {&c->fix, h.M ? ((size_t)h.T + 3) / 4 * 16 + I * h.T * 4 : 0},  // per-tile work lists of k_skin_fix
     };
@@ -405,6 +336,18 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
             skinrt_destroy_crowd(c);
             return fail(SKINRT_E_NOMEM, std::string("hipMalloc of crowd buffers: ") + hipGetErrorString(e));
         }
+    }
+    {   // the three output arrays: placed over the HBM's regions and measured (placement.hip)
+        const size_t out_bytes = I * h.V * 12;
+        void *p = nullptr, *n = nullptr, *t = nullptr;
+        hipError_t e = allocate_outputs(ctx->cfg.device, out_bytes, h.V, instances, ctx->cfg.output_placement, ctx->stream, &p, &n, &t, &c->place);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            skinrt_destroy_crowd(c);
+            return fail(e == hipErrorOutOfMemory ? SKINRT_E_NOMEM : SKINRT_E_DEVICE, std::string("output arrays: ") + hipGetErrorString(e));
+        }
+        c->pos.p = p; c->nrm.p = n; c->tan.p = t;
+        c->pos.bytes = c->nrm.bytes = c->tan.bytes = out_bytes;
     }
     for (auto& e : c->ev) {
         if (hipEventCreate(&e) != hipSuccess) {
@@ -422,13 +365,12 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
         return fail(SKINRT_E_DEVICE, std::string("crowd initialisation: ") + hipGetErrorString(e));
     }
     c->plan = plan_skin(h, instances, ctx->cfg);
-    {
-        hipError_t pe = tune_output_placement(c);  // leaves the morph weights zero
-        if (pe == hipSuccess && h.M) pe = launch_fill_morph_weights(c->mw.as<float>(), rig->default_mw.as<float>(), instances, h.M, ctx->stream);
-        if (pe == hipSuccess) pe = hipStreamSynchronize(ctx->stream);
-        if (pe != hipSuccess) {
+    // the loader-wave kernel's LDS need grows with the longest pair list of a tile: refuse here, with a
+    // reason, what skinrt_evaluate could only report as a failed launch
+    if ((c->plan.kinds & 3u) || !c->plan.v2) {
+        if (c->plan.lds_bytes > 64 * 1024) {
             skinrt_destroy_crowd(c);
-            return fail(SKINRT_E_DEVICE, std::string("crowd initialisation (output placement): ") + hipGetErrorString(pe));
+            return fail(SKINRT_E_LIMIT, "a vertex tile is touched by too many morph targets for the loader-wave skinning kernel's LDS (about 680 per 256 vertices)");
         }
     }
     const bool fits = (size_t)h.N * 48 <= 48 * 1024;
@@ -469,7 +411,12 @@ int skinrt_set_morph_weights(skinrt_crowd* c, const float* weights) {
 
 int skinrt_set_root_transforms(skinrt_crowd* c, const float* matrices) {
     if (int rc = check_crowd(c)) return rc;
-    if (!matrices) { c->has_root = false; return SKINRT_OK; }
+    if (!matrices) {
+        HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+        HIP_TRY(hipStreamSynchronize(c->ctx->stream));  // an evaluate in flight was enqueued with the old setting
+        c->has_root = false;
+        return SKINRT_OK;
+    }
     std::vector<float> rows;
     try { rows.resize((size_t)c->I * 12); } catch (const std::bad_alloc&) { return fail(SKINRT_E_NOMEM, "out of host memory"); }
     for (uint32_t i = 0; i < c->I; ++i) {
@@ -479,7 +426,9 @@ int skinrt_set_root_transforms(skinrt_crowd* c, const float* matrices) {
             for (int k = 0; k < 4; ++k) rows[(size_t)i * 12 + r * 4 + k] = m[k * 4 + r];
     }
     HIP_TRY(hipSetDevice(c->ctx->cfg.device));
-    HIP_TRY(hipMemcpy(c->root.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+    // stream-ordered like the other setters: an evaluate already enqueued reads root[] before this copy
+    HIP_TRY(hipMemcpyAsync(c->root.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, c->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));  // host buffer is borrowed for the call only
     c->has_root = true;
     return SKINRT_OK;
 }
@@ -528,6 +477,13 @@ int skinrt_last_stage_ms(skinrt_crowd* c, float ms[4]) {
 int skinrt_get_stream(skinrt_ctx* ctx, void** out_stream) {
     if (!ctx || !out_stream) return fail(SKINRT_E_INVALID, "skinrt_get_stream: NULL argument");
     *out_stream = ctx->stream;
+    return SKINRT_OK;
+}
+
+int skinrt_get_output_placement(skinrt_crowd* c, skinrt_placement_info* out_info) {
+    if (int rc = check_crowd(c)) return rc;
+    if (!out_info) return fail(SKINRT_E_INVALID, "out_info is NULL");
+    *out_info = c->place;
     return SKINRT_OK;
 }
 

@@ -1236,7 +1236,7 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
     if (cr.I == 0 || rig.T == 0) return hipSuccess;
     // what the kernel's indexing assumes about the plan (checked here, on the host, every launch)
     if (plan.batch == 0 || plan.range == 0 || plan.range > 256 || plan.range % plan.batch != 0 ||
-        (uint64_t)plan.ranges * plan.range < cr.I || plan.lds_bytes > 64 * 1024 ||
+        (uint64_t)plan.ranges * plan.range < cr.I ||
         plan.tile_chunks == 0 || 8 % plan.tile_chunks != 0 ||
         (uint64_t)plan.tiles_per_chunk * plan.tile_chunks < rig.T ||
         (uint64_t)plan.ranges_per_chunk * (8 / plan.tile_chunks) < plan.ranges)
@@ -1278,6 +1278,9 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
             e = hipGetLastError();
         }
     }
+    // the loader-wave kernel's LDS need is checked only when it is launched at all (skinrt_create_crowd refuses such rigs)
+    const bool need_k_skin = (plan.kinds & 3u) || (!plan.v2 && (plan.kinds & 4u));
+    if (e == hipSuccess && need_k_skin && plan.lds_bytes > 64 * 1024) return hipErrorInvalidValue;
     if (e == hipSuccess && ((plan.kinds & 2u) || (!plan.v2 && (plan.kinds & 4u))))
         e = plan.exact ? launch_skin_k<true, true>(rig, cr, plan, s) : launch_skin_k<false, true>(rig, cr, plan, s);
     if (e == hipSuccess && (plan.kinds & 1u))

@@ -1,0 +1,156 @@
+// placement.hip — where the three output arrays (positions / normals / tangents) live in HBM.
+//
+// Measured on MI355X (tools/ubench/place_probe{,2,3}.hip, profiles/r02_placement.txt): the 288 GiB of
+// HBM3E behave as THREE regions of one third of the physical address space each (96 GiB; 36 GB
+// stacks are three ranks deep).  Write streams confined to one region top out at ~5.4 TB/s whatever
+// the store shape, occupancy or offsets inside the region; the same streams spread over two regions
+// reach 6.7-6.9 TB/s and over three 6.95-7.0 TB/s.  The skin stage writes three equal streams, so the
+// natural layout is one array per region.  hipMalloc gives no control over physical placement, but
+// the VRAM manager hands out memory lowest-first: the amount in use (hipMemGetInfo) is the
+// allocation frontier.  So the arrays are steered: positions where the frontier is, a filler
+// allocation up to the next region boundary, normals, a filler up to the next boundary, tangents;
+// the fillers are freed again at once (a transient reservation, never touched).  The result is then
+// MEASURED with the stage's own store pattern (all three arrays together against one array alone),
+// and the measurement is what skinrt_get_output_placement reports.  No retry loop, no second set.
+#include "device_types.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace skinrt {
+
+namespace {
+
+typedef float float3v __attribute__((ext_vector_type(3)));
+
+// The skin stage's output address pattern with no arithmetic: block = (tile of 256 vertices, range of
+// 80 instances), consecutive blocks round-robin over the 8 XCDs, per instance every wave writes
+// 768 contiguous bytes to each array (global_store_dwordx3, streaming).
+template <int ARRAYS>
+__global__ __launch_bounds__(256) void k_store_probe(char* a0, char* a1, char* a2, uint32_t V, uint32_t T, uint32_t I,
+                                                     uint32_t R, uint32_t ranges) {
+    const uint32_t Tx = (T + 7) / 8, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const uint32_t tile = xcd * Tx + k % Tx, rng = k / Tx;
+    if (tile >= T || rng >= ranges) return;
+    if (tile * kTileVerts + threadIdx.x >= V) return;
+    const uint32_t off = (tile * kTileVerts + threadIdx.x) * 12;
+    const float3v d = {0.0f, 0.0f, 0.0f};
+    const uint32_t i1 = min(I, (rng + 1) * R);
+    const size_t istride = (size_t)V * 12;
+    for (uint32_t i = rng * R; i < i1; ++i) {
+        char* p = a0 + (size_t)i * istride;
+        asm volatile("global_store_dwordx3 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(d), "s"(p) : "memory");
+        if (ARRAYS == 3) {
+            char* n = a1 + (size_t)i * istride;
+            char* t = a2 + (size_t)i * istride;
+            asm volatile("global_store_dwordx3 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(d), "s"(n) : "memory");
+            asm volatile("global_store_dwordx3 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(d), "s"(t) : "memory");
+        }
+    }
+}
+
+hipError_t time_probe(int arrays, char* a0, char* a1, char* a2, uint32_t V, uint32_t I, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                      float* best_ms) {
+    const uint32_t T = (V + kTileVerts - 1) / kTileVerts, R = 80, ranges = (I + R - 1) / R;
+    const dim3 grid(8u * ((T + 7) / 8) * ranges), block(256);
+    *best_ms = 3.0e38f;
+    for (int rep = 0; rep < 3; ++rep) {  // the first run also warms the page tables
+        hipError_t e = hipEventRecord(e0, s);
+        if (e != hipSuccess) return e;
+        if (arrays == 1) hipLaunchKernelGGL(k_store_probe<1>, grid, block, 0, s, a0, a1, a2, V, T, I, R, ranges);
+        else hipLaunchKernelGGL(k_store_probe<3>, grid, block, 0, s, a0, a1, a2, V, T, I, R, ranges);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) return e;
+        if (rep) *best_ms = std::min(*best_ms, ms);
+    }
+    return hipSuccess;
+}
+
+constexpr uint32_t kHbmRegions = 3;                       // MI355X: thirds of the physical address space
+constexpr size_t kSteerMinSetBytes = (size_t)1 << 30;     // smaller output sets are not worth steering
+constexpr size_t kSteerMargin = (size_t)256 << 20;        // land this far past a predicted boundary
+
+bool device_has_regions(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+}
+
+}  // namespace
+
+hipError_t allocate_outputs(int device, size_t bytes_each, uint32_t V, uint32_t I, uint32_t mode, hipStream_t s,
+                            void** pos, void** nrm, void** tan, skinrt_placement_info* info) {
+    std::memset(info, 0, sizeof *info);
+    *pos = *nrm = *tan = nullptr;
+    if (bytes_each == 0) return hipSuccess;
+    auto release_all = [&]() {
+        for (void** p : {pos, nrm, tan}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    };
+    auto plain = [&]() -> hipError_t {
+        for (void** p : {pos, nrm, tan}) {
+            hipError_t e = hipMalloc(p, bytes_each);
+            if (e != hipSuccess) { release_all(); return e; }
+        }
+        return hipSuccess;
+    };
+    const bool steer = mode == 0 && 3 * bytes_each >= kSteerMinSetBytes && device_has_regions(device);
+    if (!steer) return plain();
+
+    size_t free_b = 0, total_b = 0;
+    hipError_t e = hipMemGetInfo(&free_b, &total_b);
+    if (e != hipSuccess) return e;
+    const size_t region = total_b / kHbmRegions;
+    const size_t r0 = std::min<size_t>((total_b - free_b) / region, kHbmRegions - 1);
+    std::vector<void*> fillers;
+    // occupy everything up to `target` bytes in use, so that the next allocation starts there
+    auto advance_to = [&](size_t target) {
+        size_t f = 0, t = 0;
+        if (hipMemGetInfo(&f, &t) != hipSuccess) { (void)hipGetLastError(); return; }
+        const size_t front = t - f;
+        if (target <= front || target + bytes_each + kSteerMargin > t) return;
+        void* filler = nullptr;
+        if (hipMalloc(&filler, target - front) != hipSuccess) { (void)hipGetLastError(); return; }
+        fillers.push_back(filler);
+        info->filler_bytes += target - front;
+    };
+    e = hipMalloc(pos, bytes_each);
+    if (e == hipSuccess) {
+        if (r0 + 1 < kHbmRegions) advance_to((r0 + 1) * region + kSteerMargin);
+        e = hipMalloc(nrm, bytes_each);
+    }
+    if (e == hipSuccess) {
+        if (r0 + 2 < kHbmRegions) advance_to((r0 + 2) * region + kSteerMargin);
+        e = hipMalloc(tan, bytes_each);
+    }
+    for (void* f : fillers) (void)hipFree(f);
+    if (e != hipSuccess) {  // no room for the detour: take what a plain allocation gives
+        (void)hipGetLastError();
+        release_all();
+        info->filler_bytes = 0;
+        return plain();
+    }
+    info->strategy = fillers.empty() ? 0u : 1u;
+
+    // measure what came out of it
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float together = 0.0f, alone = 0.0f;
+    if (e == hipSuccess) e = time_probe(3, (char*)*pos, (char*)*nrm, (char*)*tan, V, I, s, e0, e1, &together);
+    if (e == hipSuccess) e = time_probe(1, (char*)*pos, nullptr, nullptr, V, I, s, e0, e1, &alone);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) { release_all(); return e; }
+    info->probe_together_ms = together;
+    info->probe_alone_ms = alone;
+    info->spread_gain = together > 0.0f ? 3.0f * alone / together : 0.0f;
+    info->probe_GBps = together > 0.0f ? (float)(3.0 * (double)bytes_each / (together * 1e-3) / 1e9) : 0.0f;
+    return hipSuccess;
+}
+
+}  // namespace skinrt
