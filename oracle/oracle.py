@@ -139,6 +139,20 @@ class Oracle:
         self.lib.orc_decompose(self._p(m), self._p(t), self._p(q), self._p(s))
         return t, q, s
 
+    def calculate_tangent(self, mode, positions, indices=None):
+        """calculate_tangent (renderer-asset/src/tangent.rs:15-58); [V][3]."""
+        p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        idx = None if indices is None else np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        out = np.zeros(p.shape, dtype=self.real)
+        rc = self.lib.orc_calculate_tangent(C.c_uint32(mode), p.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(p.shape[0]),
+                                            None if idx is None else idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            C.c_uint32(0 if idx is None else idx.shape[0]), self._p(out))
+        if rc == -1:
+            raise NotImplementedError("TriangleStrip: todo!() in the reference (tangent.rs:26)")
+        if rc == -2:
+            raise IndexError("vertex index out of range (reference: index panic)")
+        return out
+
     # --- whole path --------------------------------------------------------------------------
     def evaluate(self, rig: RigData, tau, clip_id=None, morph_weights=None, root=None, *,
                  cubic_quirk=1, normalize_outputs=0, want=("world", "palette", "key_index", "position",

@@ -322,6 +322,58 @@ ORC_API void orc_skin_vertex(const real* pal, uint32_t sets, const uint16_t* con
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* calculate_tangent — renderer-asset/src/tangent.rs:15-58 (load time).
+ * calculate_triangle_tangent (:5-12): normalize((p2 - p1) x (p0 - p1)).  glam 0.29 scalar Vec3:
+ *   cross     = (a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y)
+ *   normalize = v * (1 / sqrt((v.x*v.x + v.y*v.y) + v.z*v.z))            (mul by length_recip)
+ * Triangles in order, each unit normal ADDED to its three vertices in corner order (:38, :49; a vertex
+ * named twice gets it twice), then every vertex sum normalised (:54-56; zero sums give NaN).
+ * mode: PrimitiveAssetMode ordinal; 0-2 (points, lines) have no faces (:23-25); 3 (TriangleStrip) is
+ * todo!() (:26) -> returns -1; an index >= vertices is a panic in the reference -> returns -2. */
+static real rlen_recip(const real* v) {
+#if defined(ORC_DOUBLE)
+    return (real)1.0 / sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+#else
+    return (real)1.0 / sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+#endif
+}
+ORC_API int orc_calculate_tangent(uint32_t mode, const float* positions, uint32_t vertices, const uint32_t* indices,
+                                  uint32_t index_count, real* out) {
+    if (mode == 3) return -1;
+    for (size_t i = 0; i < (size_t)vertices * 3; ++i) out[i] = (real)0.0;
+    if (mode == 4) {
+        uint32_t triangles = (indices ? index_count : vertices) / 3;
+        for (uint32_t f = 0; f < triangles; ++f) {
+            uint32_t ix[3];
+            for (int k = 0; k < 3; ++k) {
+                ix[k] = indices ? indices[3 * f + k] : 3 * f + k;
+                if (ix[k] >= vertices) return -2;
+            }
+            real p0[3], p1[3], p2[3], a[3], b[3], c[3];
+            for (int e = 0; e < 3; ++e) {
+                p0[e] = (real)positions[(size_t)ix[0] * 3 + e];
+                p1[e] = (real)positions[(size_t)ix[1] * 3 + e];
+                p2[e] = (real)positions[(size_t)ix[2] * 3 + e];
+                a[e] = p2[e] - p1[e];
+                b[e] = p0[e] - p1[e];
+            }
+            c[0] = a[1] * b[2] - b[1] * a[2];
+            c[1] = a[2] * b[0] - b[2] * a[0];
+            c[2] = a[0] * b[1] - b[0] * a[1];
+            real r = rlen_recip(c);
+            real n[3] = {c[0] * r, c[1] * r, c[2] * r};
+            for (int k = 0; k < 3; ++k)
+                for (int e = 0; e < 3; ++e) out[(size_t)ix[k] * 3 + e] = out[(size_t)ix[k] * 3 + e] + n[e];
+        }
+    }
+    for (uint32_t v = 0; v < vertices; ++v) {
+        real r = rlen_recip(out + (size_t)v * 3);
+        for (int e = 0; e < 3; ++e) out[(size_t)v * 3 + e] = out[(size_t)v * 3 + e] * r;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
 typedef struct orc_crowd_in {
     uint32_t instances;
     const float* tau;            /* [I] */

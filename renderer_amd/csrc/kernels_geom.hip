@@ -10,7 +10,6 @@
 // result is bit-equal to the sequential loop.  Compiled with -ffp-contract=off (glam's scalar Vec3
 // does separate multiplies and adds).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include "device_types.hpp"
 
@@ -20,11 +19,18 @@ namespace {
 
 __device__ __forceinline__ uint32_t corner_vertex(const uint32_t* __restrict__ indices, uint32_t c) { return indices ? indices[c] : c; }
 
+// A face with a corner index >= vertices touches nothing (the host entry point rejects such input before
+// any launch — the reference panics on it; the device-pointer entry point cannot look at the indices,
+// so the kernels must be safe for them).
+__device__ __forceinline__ bool face_valid(const uint32_t* __restrict__ indices, uint32_t f, uint32_t vertices) {
+    return corner_vertex(indices, 3 * f) < vertices && corner_vertex(indices, 3 * f + 1) < vertices && corner_vertex(indices, 3 * f + 2) < vertices;
+}
+
 // unit normal of face f: normalize((p2 - p1) x (p0 - p1)), glam operation order (tangent.rs:32-41)
 __global__ __launch_bounds__(256) void k_face_normals(const float* __restrict__ pos, const uint32_t* __restrict__ indices,
-                                                      uint32_t faces, float* __restrict__ fn) {
+                                                      uint32_t faces, uint32_t vertices, float* __restrict__ fn) {
     const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= faces) return;
+    if (f >= faces || !face_valid(indices, f, vertices)) return;
     const uint32_t i0 = corner_vertex(indices, 3 * f), i1 = corner_vertex(indices, 3 * f + 1), i2 = corner_vertex(indices, 3 * f + 2);
     const float* p0 = pos + (size_t)i0 * 3; const float* p1 = pos + (size_t)i1 * 3; const float* p2 = pos + (size_t)i2 * 3;
     const float a[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
@@ -34,15 +40,16 @@ __global__ __launch_bounds__(256) void k_face_normals(const float* __restrict__ 
     fn[(size_t)f * 3 + 0] = c[0] * r; fn[(size_t)f * 3 + 1] = c[1] * r; fn[(size_t)f * 3 + 2] = c[2] * r;
 }
 
-__global__ __launch_bounds__(256) void k_corner_count(const uint32_t* __restrict__ indices, uint32_t corners, uint32_t* __restrict__ cnt) {
+__global__ __launch_bounds__(256) void k_corner_count(const uint32_t* __restrict__ indices, uint32_t corners, uint32_t vertices,
+                                                      uint32_t* __restrict__ cnt) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c < corners) atomicAdd(&cnt[corner_vertex(indices, c)], 1u);
+    if (c < corners && face_valid(indices, c / 3, vertices)) atomicAdd(&cnt[corner_vertex(indices, c)], 1u);
 }
 
-__global__ __launch_bounds__(256) void k_corner_fill(const uint32_t* __restrict__ indices, uint32_t corners, const uint32_t* __restrict__ start,
-                                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ adj) {
+__global__ __launch_bounds__(256) void k_corner_fill(const uint32_t* __restrict__ indices, uint32_t corners, uint32_t vertices,
+                                                     const uint32_t* __restrict__ start, uint32_t* __restrict__ cursor, uint32_t* __restrict__ adj) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= corners) return;
+    if (c >= corners || !face_valid(indices, c / 3, vertices)) return;
     const uint32_t v = corner_vertex(indices, c);
     adj[start[v] + atomicAdd(&cursor[v], 1u)] = c;
 }
@@ -69,38 +76,90 @@ __global__ __launch_bounds__(256) void k_vertex_sum(uint32_t vertices, const uin
     out[(size_t)v * 3 + 0] = s0 * r; out[(size_t)v * 3 + 1] = s1 * r; out[(size_t)v * 3 + 2] = s2 * r;
 }
 
+// Exclusive prefix sum of n counters (integers: exact in any order).  Three small kernels instead of a
+// library scan: no temporary-storage query, no alignment rules, nothing that could allocate.
+constexpr uint32_t kScanChunk = 1024;  // elements per block of k_scan_chunks
+__global__ __launch_bounds__(256) void k_scan_chunks(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out,
+                                                     uint32_t* __restrict__ chunk_sum) {
+    __shared__ uint32_t part[256];
+    const uint32_t t = threadIdx.x, base = blockIdx.x * kScanChunk + t * 4;
+    uint32_t v[4], run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? in[base + k] : 0u; run += v[k]; }
+    part[t] = run;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {  // inclusive scan of the 256 thread totals
+        const uint32_t x = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    uint32_t excl = part[t] - run;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k < n) out[base + k] = excl; excl += v[k]; }
+    if (t == 255) chunk_sum[blockIdx.x] = part[255];
+}
+// one block: chunk_sum[] -> its own exclusive scan, in place
+__global__ __launch_bounds__(256) void k_scan_sums(uint32_t* __restrict__ chunk_sum, uint32_t chunks) {
+    __shared__ uint32_t part[256];
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < chunks; b0 += 256) {
+        const uint32_t t = threadIdx.x, i = b0 + t;
+        const uint32_t v = i < chunks ? chunk_sum[i] : 0u;
+        part[t] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256; d <<= 1) {
+            const uint32_t x = t >= d ? part[t - d] : 0u;
+            __syncthreads();
+            part[t] += x;
+            __syncthreads();
+        }
+        if (i < chunks) chunk_sum[i] = carry + part[t] - v;
+        carry += part[255];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ chunk_sum) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] += chunk_sum[i / kScanChunk];
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 }  // namespace
 
 // pos: [V][3] device; indices: [corners] device or nullptr (then corner c is vertex c); corners = 3 * faces;
 // work: device scratch of tangent_work_bytes(V, corners); out: [V][3] device
+// layout of the work area: every table starts on a 256-byte boundary
 size_t tangent_work_bytes(uint32_t vertices, uint32_t corners) {
-    size_t scan = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)vertices + 1);
-    return ((size_t)(vertices + 1) * 3 + corners) * 4 + (size_t)corners * 4 /* face normals: corners/3*3 floats */ + scan + 256;
+    const size_t n = (size_t)vertices + 1, chunks = (n + kScanChunk - 1) / kScanChunk;
+    return 3 * align256(n * 4) + 2 * align256((size_t)corners * 4) + align256(chunks * 4);
 }
 
 hipError_t launch_tangents(const float* pos, const uint32_t* indices, uint32_t vertices, uint32_t corners, void* work, size_t work_bytes,
                            float* out, hipStream_t s) {
     if (vertices == 0) return hipSuccess;
-    uint32_t* cnt = static_cast<uint32_t*>(work);           // [V+1] corner counts, then scanned into start
-    uint32_t* start = cnt + (vertices + 1);                 // [V+1]
-    uint32_t* cursor = start + (vertices + 1);              // [V+1]
-    uint32_t* adj = cursor + (vertices + 1);                // [corners]
-    float* fn = reinterpret_cast<float*>(adj + corners);    // [faces][3]
-    void* scan_tmp = fn + corners;
-    const size_t used = (size_t)(reinterpret_cast<char*>(scan_tmp) - static_cast<char*>(work));
-    if (used > work_bytes) return hipErrorInvalidValue;
-    size_t scan_bytes = work_bytes - used;
+    if (tangent_work_bytes(vertices, corners) > work_bytes || (reinterpret_cast<uintptr_t>(work) & 255u)) return hipErrorInvalidValue;
+    const uint32_t n = vertices + 1, chunks = (n + kScanChunk - 1) / kScanChunk;
+    char* w = static_cast<char*>(work);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(w);              w += align256((size_t)n * 4);        // [V+1] corner counts
+    uint32_t* start = reinterpret_cast<uint32_t*>(w);            w += align256((size_t)n * 4);        // [V+1] their exclusive scan
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(w);           w += align256((size_t)n * 4);        // [V+1]
+    uint32_t* adj = reinterpret_cast<uint32_t*>(w);              w += align256((size_t)corners * 4);  // [corners]
+    float* fn = reinterpret_cast<float*>(w);                     w += align256((size_t)corners * 4);  // [faces][3]
+    uint32_t* chunk_sum = reinterpret_cast<uint32_t*>(w);                                             // [chunks]
     const uint32_t faces = corners / 3;
-    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)(vertices + 1) * 3 * 4, s);  // cnt, start, cursor
+    // the work area keeps the last call's contents: everything read before it is written starts at zero
+    hipError_t e = hipMemsetAsync(cnt, 0, 3 * align256((size_t)n * 4), s);  // cnt, start, cursor
     if (e != hipSuccess) return e;
     if (corners) {
-        hipLaunchKernelGGL(k_face_normals, dim3((faces + 255) / 256), dim3(256), 0, s, pos, indices, faces, fn);
-        hipLaunchKernelGGL(k_corner_count, dim3((corners + 255) / 256), dim3(256), 0, s, indices, corners, cnt);
+        hipLaunchKernelGGL(k_face_normals, dim3((faces + 255) / 256), dim3(256), 0, s, pos, indices, faces, vertices, fn);
+        hipLaunchKernelGGL(k_corner_count, dim3((corners + 255) / 256), dim3(256), 0, s, indices, corners, vertices, cnt);
     }
-    e = hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cnt, start, (int)vertices + 1, s);
-    if (e != hipSuccess) return e;
-    if (corners) hipLaunchKernelGGL(k_corner_fill, dim3((corners + 255) / 256), dim3(256), 0, s, indices, corners, start, cursor, adj);
+    hipLaunchKernelGGL(k_scan_chunks, dim3(chunks), dim3(256), 0, s, cnt, n, start, chunk_sum);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, chunk_sum, chunks);
+    hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, s, start, n, chunk_sum);
+    if (corners) hipLaunchKernelGGL(k_corner_fill, dim3((corners + 255) / 256), dim3(256), 0, s, indices, corners, vertices, start, cursor, adj);
     hipLaunchKernelGGL(k_vertex_sum, dim3((vertices + 255) / 256), dim3(256), 0, s, vertices, start, adj, fn, out);
     return hipGetLastError();
 }

@@ -241,6 +241,23 @@ def test_calculate_tangent_indexed_accumulates_per_vertex():
     assert np.isnan(hostlib.calculate_tangent(0, pos)).all()   # points: zero vectors normalised -> NaN, as the reference
 
 
+def test_host_calculate_tangent_equals_the_oracle_restatement(oracle32):
+    """The product's host restatement (used by the loader for primitives and morph targets without TANGENT)
+    against oracle/skin_oracle.c orc_calculate_tangent, bit for bit: a shuffled grid, repeated corners,
+    degenerate triangles (NaN) and vertices no triangle touches."""
+    rng = np.random.default_rng(8)
+    n = 23
+    xs, ys = np.meshgrid(np.arange(n + 1, dtype=np.float32), np.arange(n + 1, dtype=np.float32))
+    pos = np.stack([xs, ys, rng.normal(scale=0.3, size=xs.shape).astype(np.float32)], axis=-1).reshape(-1, 3)
+    q = np.arange(n * n); a = (q // n) * (n + 1) + q % n
+    tris = np.concatenate([np.stack([a, a + 1, a + n + 1], 1), np.stack([a + 1, a + n + 2, a + n + 1], 1), [[5, 5, 9], [3, 3, 3]]])
+    rng.shuffle(tris)
+    idx = tris.astype(np.uint32).reshape(-1)
+    for args in ((4, pos, idx), (4, pos[:300]), (0, pos[:10]), (2, pos[:10])):
+        got, want = hostlib.calculate_tangent(*args), oracle32.calculate_tangent(*args)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.gpu
 def test_loaded_glb_evaluates_on_the_gpu(oracle32):
     spec = SPECS["c3_shape"]

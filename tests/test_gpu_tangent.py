@@ -1,12 +1,14 @@
 """calculate_tangent on the device (include/skinrt.h skinrt_calculate_tangent)
-against the host restatement of renderer-asset/src/tangent.rs:15-58 (renderer_amd/host,
-tests/test_glb_loader.py pins that one by hand-computed cases).  The sum per vertex follows the
-reference's order, so the comparison is bit for bit — NaNs included (degenerate triangles, vertices no
-triangle touches).  PARITY UNPINNED against the reference itself (no toolchain here)."""
+against the ORACLE's restatement of renderer-asset/src/tangent.rs:15-58 (oracle/skin_oracle.c
+orc_calculate_tangent; pinned by hand-computed cases in tests/test_oracle_known_answers.py).  The sum
+per vertex follows the reference's order, so the comparison is bit for bit — NaNs included (degenerate
+triangles, vertices no triangle touches).  PARITY UNPINNED against the reference itself (no toolchain
+here).  The product's own host restatement (renderer_amd/host, used by the .glb loader) is checked
+against the same oracle in tests/test_glb_loader.py."""
 import numpy as np
 import pytest
 
-from renderer_amd import abi, api, hostlib
+from renderer_amd import abi, api
 
 pytestmark = pytest.mark.gpu
 
@@ -28,30 +30,30 @@ def grid_mesh(n, rng):
     return pos, tris.astype(np.uint32).reshape(-1)
 
 
-@pytest.mark.parametrize("n", [1, 7, 64])
-def test_indexed_mesh_matches_the_sequential_loop_bit_for_bit(n):
+@pytest.mark.parametrize("n", [1, 7, 64, 1001])   # 1001: an even vertex count spanning many scan chunks
+def test_indexed_mesh_matches_the_sequential_loop_bit_for_bit(oracle32, n):
     rng = np.random.default_rng(n)
     pos, idx = grid_mesh(n, rng)
     with api.Context() as ctx:
         got = ctx.calculate_tangent(TRIANGLE_LIST, pos, idx)
-    want = hostlib.calculate_tangent(TRIANGLE_LIST, pos, idx)
+    want = oracle32.calculate_tangent(TRIANGLE_LIST, pos, idx)
     assert np.array_equal(bits(got), bits(want))
     assert np.isfinite(got).all()
 
 
-def test_unindexed_degenerate_and_untouched_vertices():
+def test_unindexed_degenerate_and_untouched_vertices(oracle32):
     rng = np.random.default_rng(3)
     pos = rng.normal(size=(3 * 50 + 2, 3)).astype(np.float32)   # the last two vertices belong to no triangle
     pos[9:12] = pos[9]                                           # a triangle with three equal corners: 0/0
     pos[30] = pos[31]                                            # a sliver
     with api.Context() as ctx:
         got = ctx.calculate_tangent(TRIANGLE_LIST, pos)
-    want = hostlib.calculate_tangent(TRIANGLE_LIST, pos)
+    want = oracle32.calculate_tangent(TRIANGLE_LIST, pos)
     assert np.array_equal(bits(got), bits(want))
     assert np.isnan(got[-1]).all() and np.isnan(got[9]).all()
 
 
-def test_high_valence_and_repeated_corners():
+def test_high_valence_and_repeated_corners(oracle32):
     # a fan of 300 triangles around vertex 0 (its corner list is sorted per vertex on the device), plus
     # triangles that name a vertex twice (the sequential loop then adds that normal twice)
     rng = np.random.default_rng(5)
@@ -64,7 +66,7 @@ def test_high_valence_and_repeated_corners():
     idx = np.concatenate([fan, odd]).astype(np.uint32).reshape(-1)
     with api.Context() as ctx:
         got = ctx.calculate_tangent(TRIANGLE_LIST, pos, idx)
-    want = hostlib.calculate_tangent(TRIANGLE_LIST, pos, idx)
+    want = oracle32.calculate_tangent(TRIANGLE_LIST, pos, idx)
     assert np.array_equal(bits(got), bits(want))
 
 
@@ -84,7 +86,7 @@ def test_modes_and_errors():
         assert ctx.calculate_tangent(TRIANGLE_LIST, np.zeros((0, 3), np.float32)).shape == (0, 3)
 
 
-def test_million_vertex_mesh_and_its_rate(capsys):
+def test_million_vertex_mesh_and_its_rate(oracle32, capsys):
     """C5-sized mesh (1M vertices, 2M triangles): bit-equal to the host loop; the kernels' time is printed
     (HBM-bound integer/float gather work: positions 12 B + indices 12 B read per triangle corner set,
     face normals written and read back once per corner)."""
@@ -93,7 +95,7 @@ def test_million_vertex_mesh_and_its_rate(capsys):
     with api.Context() as ctx:
         ctx.calculate_tangent(TRIANGLE_LIST, pos, idx)                      # warm-up
         got, ms = ctx.calculate_tangent(TRIANGLE_LIST, pos, idx, with_ms=True)
-    want = hostlib.calculate_tangent(TRIANGLE_LIST, pos, idx)
+    want = oracle32.calculate_tangent(TRIANGLE_LIST, pos, idx)
     assert np.array_equal(bits(got), bits(want))
     V, C3 = pos.shape[0], idx.shape[0]
     algorithmic = V * 12 + C3 * 4 + V * 12        # positions and indices in, tangents out

@@ -290,3 +290,40 @@ def test_fp32_oracle_distance_to_fp64(oracle32, oracle64, capsys):
     with capsys.disabled():
         print(f"\n[oracle] fp32 vs fp64 position: max abs {err.max():.3e}, budget use {rel.max() / 1e-5:.3f} of 1e-5 rel / 1e-6 abs")
     assert rel.max() < 1e-5
+
+
+# ---- calculate_tangent (renderer-asset/src/tangent.rs:15-58) ---------------------------------------
+def test_tangent_single_triangle_and_shared_vertex(oracle32):
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    # triangle (p0,p1,p2): (p2-p1) x (p0-p1) = (-1,1,0) x (-1,0,0) = (0,0,1), already unit
+    t = oracle32.calculate_tangent(4, pos[:3])
+    assert t.tolist() == [[0, 0, 1]] * 3
+    # second face (0,3,1): (p1-p3) x (p0-p3) = (1,0,-1) x (0,0,-1) = (0,1,0); vertices 0 and 1 get both normals
+    t = oracle32.calculate_tangent(4, pos, np.array([0, 1, 2, 0, 3, 1], np.uint32))
+    s = np.float32(1.0) * (np.float32(1.0) / np.sqrt(np.float32(2.0)))
+    assert t[0].tolist() == [0.0, float(s), float(s)] and t[1].tolist() == [0.0, float(s), float(s)]
+    assert t[2].tolist() == [0, 0, 1] and t[3].tolist() == [0, 1, 0]
+
+
+def test_tangent_order_of_accumulation_and_repeated_corner(oracle32):
+    # a vertex named twice in a triangle receives that normal twice (tangent.rs:38 iterates the three indices)
+    pos = np.array([[0, 0, 0], [2, 0, 0], [0, 3, 0], [0, 0, 5]], np.float32)
+    one = oracle32.calculate_tangent(4, pos, np.array([0, 1, 2], np.uint32))
+    assert one[0].tolist() == [0, 0, 1]            # (p2-p1) x (p0-p1) = (-2,3,0) x (-2,0,0) = (0,0,6) -> (0,0,1)
+    # faces (0,1,2) -> (0,0,1) and (0,3,1): (p1-p3) x (p0-p3) = (2,0,-5) x (0,0,-5) = (0,10,0) -> (0,1,0);
+    # vertex 0 sums (0,0,1) + (0,1,0), then a degenerate face (0,0,0) adds NaN to vertex 0 only
+    t = oracle32.calculate_tangent(4, pos, np.array([0, 1, 2, 0, 3, 1, 0, 0, 0], np.uint32))
+    assert np.isnan(t[0]).all() and np.isfinite(t[1:]).all()
+
+
+def test_tangent_modes(oracle32):
+    pos = np.eye(3, dtype=np.float32)
+    for mode in (0, 1, 2):
+        assert np.isnan(oracle32.calculate_tangent(mode, pos)).all()    # zero sums normalise to NaN (tangent.rs:54-56)
+    with pytest.raises(NotImplementedError):
+        oracle32.calculate_tangent(3, pos)                              # todo!() (tangent.rs:26)
+    with pytest.raises(IndexError):
+        oracle32.calculate_tangent(4, pos, np.array([0, 1, 3], np.uint32))
+    # trailing vertices that do not fill a triangle are ignored (positions.len() / 3, tangent.rs:41)
+    t = oracle32.calculate_tangent(4, np.concatenate([pos, pos[:2]]))
+    assert np.isfinite(t[:3]).all() and np.isnan(t[3:]).all()
