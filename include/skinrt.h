@@ -310,6 +310,23 @@ SKINRT_API int skinrt_export_interleaved(skinrt_crowd* crowd, uint32_t instance,
 SKINRT_API int skinrt_calculate_tangent(skinrt_ctx* ctx, uint32_t mode, const float* positions, uint32_t vertex_count,
                              const uint32_t* indices, uint32_t index_count, float* out, float* out_device_ms);
 
+/* The same computation for callers that must not allocate device memory (code under HIP graph capture,
+ * serving loops and harnesses that forbid hipMalloc): NO COUNTERPART IN THE REFERENCE.  positions,
+ * indices and out are DEVICE pointers the caller owns; the work area (corner buckets, face normals,
+ * scan sums) is a 16 MiB array inside the library's code object, one copy per GPU, held until the
+ * process ends.  Limits: vertex_count <= SKINRT_TANGENT_NOALLOC_MAX_VERTICES and at most
+ * SKINRT_TANGENT_NOALLOC_MAX_INDICES corners, else SKINRT_E_LIMIT.  The call enqueues kernels and one
+ * hipMemsetAsync on the ctx stream and returns; it calls no hipMalloc / hipFree and does not
+ * synchronise (out is defined after skinrt_synchronize).  Every call on a GPU shares that GPU's work
+ * area: calls that overlap on one GPU — two ctx on one device, or another thread — race.  The indices
+ * cannot be inspected on the host: a triangle with an index >= vertex_count contributes nothing
+ * (skinrt_calculate_tangent rejects such input with SKINRT_E_INVALID instead).  Same results, bit for bit,
+ * as skinrt_calculate_tangent on valid input. */
+#define SKINRT_TANGENT_NOALLOC_MAX_VERTICES 262144u
+#define SKINRT_TANGENT_NOALLOC_MAX_INDICES 1572864u
+SKINRT_API int skinrt_calculate_tangent_noalloc(skinrt_ctx* ctx, uint32_t mode, const float* dev_positions, uint32_t vertex_count,
+                                     const uint32_t* dev_indices, uint32_t index_count, float* dev_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,7 @@ EXPORTS = [
     "skinrt_get_positions", "skinrt_get_normals", "skinrt_get_tangents", "skinrt_get_aabbs",
     "skinrt_get_palette", "skinrt_get_world", "skinrt_get_keyframe_index", "skinrt_download",
     "skinrt_export_skin_uniform", "skinrt_export_interleaved", "skinrt_calculate_tangent",
+    "skinrt_calculate_tangent_noalloc",
 ]
 
 
@@ -79,6 +80,7 @@ def load_library() -> C.CDLL:
         "skinrt_export_skin_uniform": [vp, C.c_uint32, vp],
         "skinrt_export_interleaved": [vp, C.c_uint32, C.c_uint32, vp, vp],
         "skinrt_calculate_tangent": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(C.c_float)],
+        "skinrt_calculate_tangent_noalloc": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp],
     }
     for g in ("positions", "normals", "tangents", "aabbs", "palette", "world", "keyframe_index"):
         sigs[f"skinrt_get_{g}"] = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
@@ -151,6 +153,13 @@ class Context:
                                                  None if idx is None else idx.ctypes.data_as(C.c_void_p),
                                                  0 if idx is None else idx.shape[0], out.ctypes.data_as(C.c_void_p), C.byref(ms)))
         return (out, float(ms.value)) if with_ms else out
+
+    def calculate_tangent_noalloc(self, mode: int, dev_positions: int, vertex_count: int, dev_indices: int, index_count: int,
+                                  dev_out: int):
+        """skinrt_calculate_tangent_noalloc: device pointers in, device pointer out, asynchronous on the ctx stream."""
+        _check(self.lib.skinrt_calculate_tangent_noalloc(self.handle, mode, C.c_void_p(dev_positions), vertex_count,
+                                                         C.c_void_p(dev_indices) if dev_indices else None, index_count,
+                                                         C.c_void_p(dev_out)))
 
     def close(self):
         if self.handle:

@@ -216,6 +216,9 @@ int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx) {
     HIP_TRY(hipGetDeviceCount(&count));
     if (config->device < 0 || config->device >= count) return fail(SKINRT_E_DEVICE, "no such HIP device");
     HIP_TRY(hipSetDevice(config->device));
+    // the static work area of skinrt_calculate_tangent_noalloc: resolve its address on this device now (once per
+    // device); a failure is kept and reported by that entry point, it does not concern the others
+    (void)tangent_static_setup(config->device);
     skinrt_ctx* ctx = new (std::nothrow) skinrt_ctx;
     if (!ctx) return fail(SKINRT_E_NOMEM, "out of host memory");
     ctx->cfg = *config;
@@ -596,6 +599,32 @@ int skinrt_calculate_tangent(skinrt_ctx* ctx, uint32_t mode, const float* positi
     if (e1) (void)hipEventDestroy(e1);
     dpos.release(); didx.release(); dwork.release(); dout.release();
     if (e != hipSuccess) return fail(SKINRT_E_DEVICE, std::string("skinrt_calculate_tangent: ") + hipGetErrorString(e));
+    return SKINRT_OK;
+}
+
+int skinrt_calculate_tangent_noalloc(skinrt_ctx* ctx, uint32_t mode, const float* dev_positions, uint32_t vertex_count,
+                                     const uint32_t* dev_indices, uint32_t index_count, float* dev_out) {
+    if (!ctx) return fail(SKINRT_E_INVALID, "ctx is NULL");
+    if (mode > 4) return fail(SKINRT_E_INVALID, "mode must be a PrimitiveAssetMode ordinal (0..4)");
+    if (mode == 3) return fail(SKINRT_E_INVALID, "TriangleStrip: todo!() in the reference (tangent.rs:27)");
+    if (vertex_count == 0) return SKINRT_OK;
+    if (!dev_positions || !dev_out) return fail(SKINRT_E_INVALID, "skinrt_calculate_tangent_noalloc: NULL pointer");
+    if (dev_indices == nullptr && index_count != 0) return fail(SKINRT_E_INVALID, "index_count without indices");
+    if (vertex_count > SKINRT_TANGENT_NOALLOC_MAX_VERTICES)
+        return fail(SKINRT_E_LIMIT, "skinrt_calculate_tangent_noalloc: more than SKINRT_TANGENT_NOALLOC_MAX_VERTICES vertices (use skinrt_calculate_tangent)");
+    uint32_t corners = 0;
+    if (mode == 4) corners = (dev_indices ? index_count : vertex_count) / 3 * 3;
+    if (corners > SKINRT_TANGENT_NOALLOC_MAX_INDICES)
+        return fail(SKINRT_E_LIMIT, "skinrt_calculate_tangent_noalloc: more than SKINRT_TANGENT_NOALLOC_MAX_INDICES indices (use skinrt_calculate_tangent)");
+    HIP_TRY(hipSetDevice(ctx->cfg.device));
+    void* work = nullptr;
+    size_t work_bytes = 0;
+    {
+        const hipError_t e = tangent_static_area(ctx->cfg.device, &work, &work_bytes);
+        if (e != hipSuccess) return fail(SKINRT_E_DEVICE, std::string("static work area not available on this device: ") + hipGetErrorString(e));
+    }
+    if (tangent_work_bytes(vertex_count, corners) > work_bytes) return fail(SKINRT_E_LIMIT, "skinrt_calculate_tangent_noalloc: input exceeds the static work area");
+    HIP_TRY(launch_tangents(dev_positions, dev_indices, vertex_count, corners, work, work_bytes, dev_out, ctx->stream));
     return SKINRT_OK;
 }
 

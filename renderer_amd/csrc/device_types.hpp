@@ -96,6 +96,8 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
 hipError_t launch_aabb_reduce(const RigDev& rig, const CrowdDev& cr, hipStream_t s);
 // kernels_geom.hip: calculate_tangent on the device (load time)
 size_t tangent_work_bytes(uint32_t vertices, uint32_t corners);
+hipError_t tangent_static_setup(int device);                             // once per device, that device current
+hipError_t tangent_static_area(int device, void** ptr, size_t* bytes);   // the device's copy of the static work area
 hipError_t launch_tangents(const float* pos, const uint32_t* indices, uint32_t vertices, uint32_t corners, void* work, size_t work_bytes,
                            float* out, hipStream_t s);
 // placement.hip: the three output arrays, steered over the HBM's regions and measured

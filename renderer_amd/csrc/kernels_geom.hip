@@ -11,6 +11,8 @@
 // does separate multiplies and adds).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "device_types.hpp"
 
 namespace skinrt {
@@ -126,7 +128,41 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, ui
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Work area of launch_tangents for the largest input skinrt_calculate_tangent_noalloc accepts.  One copy per
+// GPU the library runs on, for the life of the process; every call on a GPU shares it.
+constexpr size_t kStaticTangentBytes = (size_t)16 << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticTangentBytes];
+
+std::mutex g_scratch_mutex;
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices];       // device address of `scratch` on each device (nullptr: not resolved)
+hipError_t g_scratch_err[kMaxDevices];  // why not
+
 }  // namespace
+
+// Resolve the device address of the static work area on `device` (which must be the current device).
+// `scratch` as written in host code is a host-side handle, not a device address: every use below goes
+// through the pointer hipGetSymbolAddress returns, and each device has its own.
+hipError_t tangent_static_setup(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    g_scratch_err[device] = e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+    g_scratch_ptr[device] = ptr;
+    return hipSuccess;
+}
+
+hipError_t tangent_static_area(int device, void** ptr, size_t* bytes) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) return g_scratch_err[device] != hipSuccess ? g_scratch_err[device] : hipErrorNotInitialized;
+    *ptr = g_scratch_ptr[device];
+    *bytes = kStaticTangentBytes;
+    return hipSuccess;
+}
 
 // pos: [V][3] device; indices: [corners] device or nullptr (then corner c is vertex c); corners = 3 * faces;
 // work: device scratch of tangent_work_bytes(V, corners); out: [V][3] device
