@@ -127,7 +127,8 @@ def main():
     ap.add_argument("--instances", type=int, default=None, help="override the TOTAL instance count")
     ap.add_argument("--gather-vertices", action="store_true", help="also all-gather position buffers (xGMI-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exact", type=int, default=0, help="1: contraction-free skinning kernel (bit-equal to the oracle)")
+    ap.add_argument("--exact", type=int, default=0, choices=[0, 1, 2],
+                    help="skinrt_config.exact_arithmetic: 0 chosen per rig, 1 contraction-free kernels (bit-equal to the oracle), 2 FMA kernels")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,7 +226,7 @@ def main():
                        "morph_targets": rig_data.target_count, "channels": rig_data.max_channels,
                        "stages": "pose+morph+skin+aabb" + ("+allgather(aabb)" if world > 1 else "") +
                                  ("+allgather(positions)" if args.gather_vertices and world > 1 else ""),
-                       "exact_arithmetic": args.exact, "parallelism": f"instances sharded x{n_gpus}"},
+                       "exact_arithmetic": int(info.exact_arithmetic), "exact_arithmetic_config": args.exact, "parallelism": f"instances sharded x{n_gpus}"},
             "stage_ms": {"pose": float(stage[:, 0].mean()), "skin_morph": skin_ms,
                          "aabb_reduce": float(stage[:, 2].mean()), "device_span": float(stage[:, 3].mean())},
             "roofline": {"bound": "hbm", "kernel": "skin stage = k_skin2 + k_skin_fix (morph + linear-blend skinning + per-tile bounds)", "achieved": achieved / 1e9,

@@ -84,9 +84,14 @@ typedef struct skinrt_config {
     uint32_t normalize_outputs;
     /* 1: reject rigs the reference cannot render (joints > 128, weight sets > 1). */
     uint32_t reference_limits;
-    /* 1: the skinning kernel uses no fused multiply-add, so positions/normals/tangents are
-     *    bit-equal to the fp32 CPU restatement (oracle/); 0: FMA in the same association
-     *    (within 1e-5 rel / 1e-6 abs).  Pose stages are always contraction-free. */
+    /* Arithmetic of the skinning kernels.  1: no fused multiply-add, positions / normals / tangents are
+     *    bit-equal to the fp32 CPU restatement (oracle/).  2: FMA in the same association — within
+     *    1e-5 rel / 1e-6 abs of it on well-conditioned rigs, about 10 % faster.  0 (default): chosen per rig
+     *    at upload: FMA unless a joint's inverse bind translation exceeds 4 units in some component —
+     *    there the skinning sums cancel, fused and unfused rounding differ by more than the 1e-6
+     *    absolute bar (BASELINE config 5: a 4096-joint chain 400 units long), and the exact kernels are
+     *    used.  skinrt_rig_info.exact_arithmetic reports the choice.  Pose stages are always
+     *    contraction-free. */
     uint32_t exact_arithmetic;
     /* 0: choose per rig; 1: wavefront-per-instance pose kernel; 2: split pose kernels
      *    (sample / lane-per-instance propagate / palette) used for very deep or large rigs. */
@@ -188,6 +193,8 @@ typedef struct skinrt_rig_info {
     uint32_t max_channels;         /* Cmax */
     uint64_t morph_entries;        /* nonzero (vertex,target) pairs kept after compaction */
     uint64_t device_bytes;         /* bytes of device memory the rig occupies */
+    uint32_t exact_arithmetic;     /* 1: the skin stage runs contraction-free on this rig (skinrt_config.exact_arithmetic) */
+    float bind_extent;             /* largest |translation component| over the inverse bind matrices */
 } skinrt_rig_info;
 
 /* What skinrt_create_crowd did with the output arrays and what it measured (all zero for small crowds

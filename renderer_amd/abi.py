@@ -115,6 +115,7 @@ class RigInfo(C.Structure):
         ("level_count", C.c_uint32), ("tile_count", C.c_uint32), ("tile_vertices", C.c_uint32),
         ("max_tile_joints", C.c_uint32), ("lds_tiles", C.c_uint32), ("max_channels", C.c_uint32),
         ("morph_entries", C.c_uint64), ("device_bytes", C.c_uint64),
+        ("exact_arithmetic", C.c_uint32), ("bind_extent", C.c_float),
     ]
 
 

@@ -200,6 +200,11 @@ class Crowd:
         _check(ctx.lib.skinrt_create_crowd(ctx.handle, rig.handle, self.instances, C.byref(self.handle)))
 
     @property
+    def exact(self) -> bool:
+        """True when the skin stage runs contraction-free on this crowd's rig (bit-equal to the fp32 oracle)."""
+        return bool(self.rig.info.exact_arithmetic)
+
+    @property
     def placement(self) -> dict:
         """What skinrt_create_crowd did with the output arrays and what it measured."""
         info = PlacementInfo()

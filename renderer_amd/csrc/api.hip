@@ -172,7 +172,7 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
         p.ranges2 = I ? (I + p.range2 - 1) / p.range2 : 0;
         p.ranges_per_chunk2 = (std::max<uint32_t>(1, p.ranges2) + rcs - 1) / rcs;
     }
-    p.exact = cfg.exact_arithmetic ? 1 : 0;
+    p.exact = r.exact;  // skinrt_config.exact_arithmetic resolved per rig at compile time
     p.normalize = cfg.normalize_outputs ? 1 : 0;
     p.aabb = 0;
     p.debug = 0;
@@ -211,6 +211,7 @@ int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx) {
     if (config->struct_size != sizeof(skinrt_config)) return fail(SKINRT_E_INVALID, "skinrt_config.struct_size mismatch");
     if (config->pose_path > 2) return fail(SKINRT_E_INVALID, "skinrt_config.pose_path must be 0, 1 or 2");
     if (config->skin_path > 1) return fail(SKINRT_E_INVALID, "skinrt_config.skin_path must be 0 or 1");
+    if (config->exact_arithmetic > 2) return fail(SKINRT_E_INVALID, "skinrt_config.exact_arithmetic must be 0, 1 or 2");
     if (config->output_placement > 1) return fail(SKINRT_E_INVALID, "skinrt_config.output_placement must be 0 or 1");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));

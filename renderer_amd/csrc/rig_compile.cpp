@@ -193,6 +193,11 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
         REQUIRE(finite_all(m, 16), SKINRT_E_INVALID, "non-finite inverse bind matrix");
         REQUIRE(affine_last_row(m), SKINRT_E_NONAFFINE, "inverse bind matrix last row is not 0,0,0,1");
         rows_from_cols(m, &r.ibm[(size_t)j * 12]);
+        for (int e = 12; e < 15; ++e) r.bind_extent = std::max(r.bind_extent, std::fabs(m[e]));
+    }
+    {
+        const uint32_t mode = cfg ? cfg->exact_arithmetic : 0;
+        r.exact = mode == 1 ? 1u : (mode == 2 ? 0u : (r.bind_extent > kExactBindExtent ? 1u : 0u));
     }
 
     // ---- mesh ------------------------------------------------------------------------------
@@ -384,6 +389,8 @@ void fill_rig_info(const CompiledRig& r, uint64_t device_bytes, skinrt_rig_info*
     info->tile_count = r.T; info->tile_vertices = kTileVerts; info->max_tile_joints = r.max_tile_joints_any;
     info->lds_tiles = r.lds_tiles; info->max_channels = r.Cmax; info->morph_entries = r.morph_entries;
     info->device_bytes = device_bytes;
+    info->exact_arithmetic = r.exact;
+    info->bind_extent = r.bind_extent;
 }
 
 }  // namespace skinrt

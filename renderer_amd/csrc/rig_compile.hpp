@@ -12,6 +12,10 @@ namespace skinrt {
 constexpr uint32_t kTileVerts = 256;   // vertices per skinning tile = threads per block
 constexpr uint32_t kTileJointCap = 64; // largest tile-local joint list that is LDS-staged
 constexpr uint32_t kPalFloats = 24;    // palette entry: 3x4 joint rows + 3x4 normal rows
+// Joints farther than this from the origin of their bind space make the skinning sums cancel: a fused and an
+// unfused multiply-add then differ by a few ulp(extent) ~ 2.4e-7 * extent, which at 4 units reaches the
+// 1e-6 absolute parity bar.  Beyond it skinrt_config.exact_arithmetic = 0 selects the contraction-free kernels.
+constexpr float kExactBindExtent = 4.0f;
 
 // one animation channel, keyframes in the shared times[] / values[] pools
 struct ChanRec {
@@ -50,6 +54,9 @@ constexpr uint32_t kMorphSlots = SKINRT_MORPH_SLOTS;  // LDS slots per wave: act
 struct CompiledRig {
     uint32_t N = 0, J = 0, V = 0, K = 0, M = 0, clips = 0, Cmax = 0, levels = 0, T = 0;
     uint32_t tangent_stride = 3;
+    // skin-stage arithmetic chosen for this rig (skinrt_config.exact_arithmetic; 0 = by bind_extent)
+    uint32_t exact = 0;
+    float bind_extent = 0.0f;           // largest |translation component| of an inverse bind matrix
     // nodes (DFS pre-order)
     std::vector<int32_t> parent;        // [N]
     std::vector<float> rest_trs;        // [N][10] t3 q4 s3 (Matrix nodes: decomposed, node.rs:76-82)

@@ -17,12 +17,16 @@ from tests.helpers import assert_close, assert_equal
 pytestmark = pytest.mark.gpu
 
 
-def run_full(oracle32, name, samples, conditioned=False, oracle64=None):
+def run_full(oracle32, name, samples, conditioned=False, oracle64=None, exact=None, first=0, count=None, **cfg):
+    """exact: None = what the library chooses for the rig (exact_arithmetic=0), True = forced exact
+    (bit-equal skinned outputs expected), False = forced FMA.  first/count: a shard of the crowd."""
     spec = synth.CONFIGS[name]
     rig = synth.make_rig(spec)
-    n = spec.instances
-    crowd = synth.make_crowd(spec, rig, instances=n)
-    with api.Context() as ctx:
+    n = spec.instances if count is None else count
+    crowd = synth.make_crowd(spec, rig, instances=n, first=first)
+    if exact is not None:
+        cfg["exact_arithmetic"] = 1 if exact else 2
+    with api.Context(**cfg) as ctx:
         r = api.Rig(ctx, rig)
         c = api.Crowd(ctx, r, n)
         c.set_clocks(crowd.tau, crowd.clip_id)
@@ -51,9 +55,14 @@ def run_full(oracle32, name, samples, conditioned=False, oracle64=None):
                 r64 = oracle64.evaluate(rig, *one, desc=desc, want=("position", "normal", "tangent"))
                 extra = 4.0 * max(float(np.abs(getattr(ref, k)[0].astype(np.float64) - getattr(r64, k)[0]).max())
                                   for k in ("position", "normal", "tangent"))
-            assert_close(pos, ref.position[0], tag + "position", atol=1e-6 + extra)
-            assert_close(c.normals(i, 1)[0], ref.normal[0], tag + "normal", atol=1e-6 + extra)
-            assert_close(c.tangents(i, 1)[0], ref.tangent[0], tag + "tangent", atol=1e-6 + extra)
+            if c.exact:  # contraction-free arithmetic (chosen by the library or forced): the oracle's bits
+                assert_equal(pos, ref.position[0], tag + "position")
+                assert_equal(c.normals(i, 1)[0], ref.normal[0], tag + "normal")
+                assert_equal(c.tangents(i, 1)[0], ref.tangent[0], tag + "tangent")
+            else:
+                assert_close(pos, ref.position[0], tag + "position", atol=1e-6 + extra)
+                assert_close(c.normals(i, 1)[0], ref.normal[0], tag + "normal", atol=1e-6 + extra)
+                assert_close(c.tangents(i, 1)[0], ref.tangent[0], tag + "tangent", atol=1e-6 + extra)
             assert_equal(bounds[i, 0], pos.min(axis=0), tag + "aabb.min")
             assert_equal(bounds[i, 1], pos.max(axis=0), tag + "aabb.max")
         c.close(); r.close()
@@ -73,8 +82,35 @@ def test_c3_avatar_x10000(oracle32):
     run_full(oracle32, "c3", spread(10000, 3))
 
 
-def test_c5_stress_x1000(oracle32, oracle64):
-    run_full(oracle32, "c5", [0, 255, 999], conditioned=True, oracle64=oracle64)
+def test_c5_stress_x1000(oracle32):
+    """C5 as the library runs it by default: the rig's joints sit hundreds of units from the origin, where
+    fused and unfused multiply-adds differ by more than the 1e-6 absolute bar, so skinrt chooses the
+    contraction-free kernels for it (skinrt_config.exact_arithmetic = 0) and the outputs carry the fp32
+    oracle's bits — inside 1e-5 rel / 1e-6 abs with nothing widened."""
+    run_full(oracle32, "c5", [0, 255, 999])
+
+
+def test_c5_stress_x1000_exact(oracle32):
+    run_full(oracle32, "c5", [1, 500, 998], exact=True)
+
+
+def test_c5_stress_x1000_forced_fma(oracle32, oracle64):
+    """exact_arithmetic = 2 forces FMA contraction on the same rig: closer to the fp64 oracle than the fp32
+    oracle is, but not inside the bar measured against the fp32 oracle — the bar is widened here by the
+    oracle's own fp32-vs-fp64 gap (see test_gpu_parity.test_c5_shape_reduced).  Kept as the measurement
+    of why the default for this rig is the exact mode."""
+    run_full(oracle32, "c5", [0, 999], conditioned=True, oracle64=oracle64, exact=False)
+
+
+@pytest.mark.parametrize("ranks,rank", [(8, 3), (2, 1)])
+def test_c4_shard_on_one_gpu(oracle32, ranks, rank):
+    """BASELINE config 4 (100,000 avatars over 2 / 4 / 8 GPUs): the shard one rank evaluates, on this GPU —
+    12,500 instances (27 GB of outputs) for 8 ranks, 50,000 (108 GB) for 2.  Instance ids are the crowd's
+    (first = rank * shard), so sampled instances are the ones rank `rank` would hand to the all-gather."""
+    from renderer_amd import shard
+    lo, hi = shard.shard_range(synth.CONFIGS["c4"].instances, rank, ranks)
+    n = hi - lo
+    run_full(oracle32, "c4", [0, 79, 80, n // 2, n - 1], first=lo, count=n)
 
 
 def test_instance_range_cap_with_batch_not_dividing_256(oracle32):

@@ -42,14 +42,61 @@ def _check_all(got, ref, exact_pose=True, exact_skin=False, tag=""):
 
 @pytest.mark.parametrize("skin_path", [0, 1])   # 0: self-staging kernel where it applies, 1: loader-wave kernel only
 @pytest.mark.parametrize("pose_path", [1, 2])
-@pytest.mark.parametrize("exact", [1, 0])
+@pytest.mark.parametrize("exact", [1, 2])   # 1: contraction-free kernels, 2: FMA kernels (0 = chosen per rig)
 def test_tiny_rig_all_features(oracle32, pose_path, exact, skin_path):
     spec = synth.tiny_spec(matrix_nodes=1)
     rig = synth.make_rig(spec)
     crowd = synth.make_crowd(spec, rig, instances=7, with_root=True)
     got = run_gpu(rig, crowd, pose_path=pose_path, exact_arithmetic=exact, skin_path=skin_path)
     ref = run_oracle(oracle32, rig, crowd)
-    _check_all(got, ref, exact_pose=True, exact_skin=bool(exact))
+    _check_all(got, ref, exact_pose=True, exact_skin=exact == 1)
+
+
+def _animated_matrix_rig(oracle32, seed):
+    """A rig whose ANIMATED joint nodes are given as NodeTransform::Matrix (node.rs:29-33): a channel then
+    forces the decomposed form (glam to_scale_rotation_translation, node.rs:73-87) and replaces one of
+    T / R / S while the other two come from the decomposition.  Rotations up to half a turn about
+    varying axes reach all four branches of Quat::from_rotation_axes; every fourth node is mirrored
+    (negative determinant: scale.x < 0).  Which channels survive differs per node and per clip, so a
+    node is decomposed in one clip and stays a matrix in the other."""
+    spec = synth.tiny_spec(seed=seed, nodes=14, joints=12, verts=300, clips=2, keys=4, frac_cubic=0.2, frac_step=0.2)
+    rig = synth.make_rig(spec)
+    rng = np.random.default_rng(seed)
+    N = rig.node_count
+    matrix = np.zeros((N, 16), np.float32)
+    has = np.zeros(N, np.uint8)
+    picked = [int(n) for n in rig.joint_node[::2]]
+    for k, n in enumerate(picked):
+        axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+        ang = rng.uniform(-np.pi, np.pi)
+        q = np.concatenate([axis * np.sin(ang / 2), [np.cos(ang / 2)]]).astype(np.float32)
+        sc = rng.uniform(0.6, 1.6, size=3).astype(np.float32)
+        if k % 4 == 3:
+            sc[0] = -sc[0]
+        matrix[n] = oracle32.trs_to_mat4(rig.translation[n], q, sc).astype(np.float32)
+        has[n] = 1
+    rig.matrix, rig.has_matrix = matrix, has
+    keep = {0: (abi.PATH_ROTATION,), 1: (abi.PATH_TRANSLATION,), 2: (abi.PATH_SCALE,), 3: (abi.PATH_TRANSLATION, abi.PATH_ROTATION)}
+    for ci, clip in enumerate(rig.clips):
+        rig.clips[ci] = [ch for ch in clip if not has[ch.target_node]
+                         or ch.path in keep[(picked.index(ch.target_node) + ci) % 4] and not (ci == 1 and picked.index(ch.target_node) % 3 == 0)]
+    return spec, rig, picked
+
+
+@pytest.mark.parametrize("pose_path", [1, 2])
+def test_animated_matrix_nodes(oracle32, pose_path):
+    spec, rig, picked = _animated_matrix_rig(oracle32, seed=33)
+    crowd = synth.make_crowd(spec, rig, instances=40, with_root=True)
+    crowd.clip_id[:3] = abi.NO_CLIP          # rest pose: every Matrix node stays a matrix
+    got = run_gpu(rig, crowd, pose_path=pose_path, exact_arithmetic=1)
+    ref = run_oracle(oracle32, rig, crowd)
+    _check_all(got, ref, exact_pose=True, exact_skin=True, tag="matrix:")
+    # the decomposition the library did at load time is the oracle's (orc_decompose), bit for bit: with the
+    # rest pose in Matrix form and the animated pose in TRS form, the two differ by rounding only
+    assert set(np.unique(crowd.clip_id[3:])) == {0, 1}
+    rest = got["world"][0]
+    moved = (got["world"][3:] != rest).any(axis=(0, 2))
+    assert moved[picked].any()
 
 
 @pytest.mark.parametrize("quirk", [1, 0])
@@ -76,34 +123,38 @@ def test_normalized_outputs(oracle32):
 
 @pytest.mark.parametrize("skin_path", [0, 1])
 @pytest.mark.parametrize("name,inst", [("c1", 1), ("c2", 64), ("c3", 6), ("c3", 300)])
-@pytest.mark.parametrize("exact", [1, 0])
+@pytest.mark.parametrize("exact", [1, 2])   # 1: contraction-free kernels, 2: FMA kernels (0 = chosen per rig)
 def test_config_shapes(oracle32, name, inst, exact, skin_path):
     spec = synth.CONFIGS[name]
     rig = synth.make_rig(spec)
     crowd = synth.make_crowd(spec, rig, instances=inst)
     got = run_gpu(rig, crowd, exact_arithmetic=exact, skin_path=skin_path)
     ref = run_oracle(oracle32, rig, crowd)
-    _check_all(got, ref, exact_skin=bool(exact), tag=name + ":")
+    _check_all(got, ref, exact_skin=exact == 1, tag=name + ":")
 
 
-@pytest.mark.parametrize("exact", [1, 0])
+@pytest.mark.parametrize("exact", [1, 0, 2])
 def test_c5_shape_reduced(oracle32, oracle64, exact):
     """C5's features at a size the oracle finishes in seconds: deep chain (split pose path chosen
-    automatically), 8 weights/vertex, compacted (sparse) morph targets."""
+    automatically), 8 weights/vertex, compacted (sparse) morph targets.  exact = 0 leaves the choice of
+    arithmetic to the library: this rig's joints sit up to 150 units from the origin, so it must pick the
+    contraction-free kernels and deliver the oracle's bits."""
     spec = synth.scaled(synth.CONFIGS["c5"], nodes=1500, joints=1500, verts=20000, targets=16, instances=3)
     rig = synth.make_rig(spec)
     crowd = synth.make_crowd(spec, rig, instances=3)
     got = run_gpu(rig, crowd, exact_arithmetic=exact)
     ref = run_oracle(oracle32, rig, crowd)
-    if exact:
+    assert got["info"].exact_arithmetic == (0 if exact == 2 else 1)
+    assert got["info"].bind_extent > 10.0
+    if exact != 2:
         _check_all(got, ref, exact_skin=True, tag="c5r:")
         return
-    # Contracted (FMA) arithmetic on this rig: joint matrices of a 1500-long chain carry translations
+    # Forced FMA arithmetic on this rig: joint matrices of a 1500-long chain carry translations
     # of tens of units, so a component that happens to land near zero is a cancelling sum and the
     # mixed 1e-5 rel / 1e-6 abs bar (relative to the RESULT) is not meaningful for it — the fp32
     # oracle itself sits farther than that from the fp64 oracle here.  The bar is therefore widened
-    # by the oracle's own rounding gap on this input (measured, not assumed); exact mode above is
-    # bit-equal on the same rig.
+    # by the oracle's own rounding gap on this input (measured, not assumed); this is why the library
+    # does not choose FMA for such a rig.
     ref64 = run_oracle(oracle64, rig, crowd)
     assert_equal(got["key_index"], ref["key_index"], "c5r:key_index")
     assert_equal(got["world"], ref["world"], "c5r:world")
@@ -122,7 +173,7 @@ def test_c5_shape_reduced(oracle32, oracle64, exact):
     (5, 1.0, "dense", 0.0),     # no idle instance at all, every instance has 5 active pairs
     (3, 1.0, "dense", 0.97),    # almost everything idle
 ])
-@pytest.mark.parametrize("exact", [1, 0])
+@pytest.mark.parametrize("exact", [1, 2])   # 1: contraction-free kernels, 2: FMA kernels (0 = chosen per rig)
 def test_morph_schedules(oracle32, targets, frac, mode, zero, exact):
     """The self-staging kernel reorders a block's instances by their set of active morph pairs, deals
     idle instances out as spacers, and hands instances it cannot serve from two LDS slots to
@@ -133,7 +184,7 @@ def test_morph_schedules(oracle32, targets, frac, mode, zero, exact):
     crowd = synth.make_crowd(spec, rig, instances=300)   # 3 blocks per tile, the last one ragged
     got = run_gpu(rig, crowd, exact_arithmetic=exact)
     ref = run_oracle(oracle32, rig, crowd)
-    _check_all(got, ref, exact_skin=bool(exact), tag="morph:")
+    _check_all(got, ref, exact_skin=exact == 1, tag="morph:")
 
 
 def test_stages_run_separately_give_the_same_frame(oracle32):
