@@ -6,12 +6,16 @@ hierarchy propagation -> joint palette -> morph + linear-blend skinning -> per-i
 (skinrt_evaluate(STAGE_ALL)), plus, for N > 1, the RCCL all-gather of the bounds.  Inputs
 (rig tables, clocks, morph weights) are resident in HBM before the timed region.
 
-Workload: BASELINE.json configs[2] (C3: VRM-shaped avatar, 60k verts, 200 joints, 4 weights,
-32 morph targets x 10,000 instances — the config the roofline target is quoted on) PER GPU:
-N=1 is C3 itself; N>1 shards 10,000*N instances over the N ranks (weak scaling, no data-path
-collective, one all-gather of the bounds per frame).  `--workload c4` runs configs[3] (the same
-avatar x 100,000 instances over the N GPUs, strong scaling); `--workload c2|c5` bench the other
-single-GPU configs.  Synthetic rigs (renderer_amd/synth.py).
+Workload at N=1: BASELINE.json configs[2] (C3: VRM-shaped avatar, 60k verts, 200 joints, 4 weights,
+32 morph targets x 10,000 instances — the config the roofline target is quoted on).  N>1: configs[3]
+(C4: the same avatar x 100,000 instances sharded over the N ranks, total fixed = strong scaling; no
+data-path collective, one RCCL all-gather of the bounds per frame); the line then also reports the
+kernels alone and the frame with the skinned vertex buffers gathered (`exchange`).  `--workload
+c2|c3|c5` with N>1 is weak scaling (the config per GPU).  Synthetic rigs (renderer_amd/synth.py).
+
+`--gpus N` (N>1) without a launcher starts the N ranks itself (torch.distributed.run children, before
+any GPU call); under a launcher WORLD_SIZE must equal N.  Either way the line's `n_gpus` is the
+number of ranks RCCL saw (`rccl_ranks`), or there is no line and the exit status is 2.
 
 Prints ONE JSON line on rank 0.
 """
@@ -118,6 +122,25 @@ def measured_bandwidth(device: int):
         if e1: hip.hipEventDestroy(e1)
 
 
+def spawn_ranks(n: int, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
+    (python -m torch.distributed.run) BEFORE this process has made any GPU call, relay their output
+    and exit with their status.  Refuses (exit 2, no JSON line) when the node has fewer GPUs."""
+    import socket
+    import subprocess
+    import torch  # device_count() does not initialise the GPU
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} asked for, {have} visible: refusing to print a line for ranks that do not exist\n")
+        sys.exit(2)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.run(cmd).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,31 +148,44 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, choices=[None, "c2", "c3", "c4", "c5"])
     ap.add_argument("--instances", type=int, default=None, help="override the TOTAL instance count")
-    ap.add_argument("--gather-vertices", action="store_true", help="also all-gather position buffers (xGMI-bound)")
+    ap.add_argument("--no-vertex-gather", action="store_true", help="N>1: skip the extra vertex all-gather measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", type=int, default=0, choices=[0, 1, 2],
                     help="skinrt_config.exact_arithmetic: 0 chosen per rig, 1 contraction-free kernels (bit-equal to the oracle), 2 FMA kernels")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        spawn_ranks(args.gpus, sys.argv[1:])  # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # one line per GPU that really runs, or none: a line must never claim more GPUs than ranks
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): refusing\n")
+        sys.exit(2)
     dist = None
     torch = None
-    if world > 1:
+    rccl_ranks = 1
+    if launched:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = max(args.gpus, world)
+        rccl_ranks = dist.get_world_size()
+        if rccl_ranks != args.gpus:
+            sys.stderr.write(f"bench.py: RCCL sees {rccl_ranks} ranks, --gpus {args.gpus}: refusing\n")
+            sys.exit(2)
+    n_gpus = rccl_ranks
 
-    # Default: weak scaling — every GPU evaluates a C3-sized shard (10,000 instances), so the job
-    # is C3 at N=1 and 80,000 avatars at N=8 (BASELINE's C4 is 100,000 over the node: 12,500 per
-    # GPU at N=8; `--workload c4` runs exactly that, total fixed = strong scaling).
-    name = args.workload or "c3"
+    # N = 1: C3 (the config the metric is quoted on).  N > 1: BASELINE's C4 — the same avatar x 100,000
+    # instances sharded over the N GPUs, total fixed (strong scaling): 50,000 per GPU at N=2, 12,500 at N=8.
+    name = args.workload or ("c3" if n_gpus == 1 else "c4")
     spec = synth.CONFIGS[name]
-    weak = name != "c4"
-    total = args.instances or (spec.instances * world if weak else spec.instances)
+    strong = name == "c4"
+    total = args.instances or (spec.instances if (strong or n_gpus == 1) else spec.instances * world)
     lo, hi = shard.shard_range(total, rank, world)
     mine = hi - lo
     rig_data = synth.make_rig(spec)
@@ -163,28 +199,35 @@ def main():
         crowd.set_morph_weights(crowd_in.morph_weights)
     V = rig_data.vertex_count
 
-    aabb_t = pos_t = None
-    if world > 1:
+    aabb_t = None
+    vert_t = []
+    if launched:
+        dev = f"cuda:{local_rank}"
         ptr, _ = crowd.device_pointer("aabbs")
-        aabb_t = torch.as_tensor(shard.DeviceArray(ptr, (mine, 6)), device=f"cuda:{local_rank}")
-        if args.gather_vertices:
-            pptr, _ = crowd.device_pointer("positions")
-            pos_t = torch.as_tensor(shard.DeviceArray(pptr, (mine, V * 3)), device=f"cuda:{local_rank}")
+        aabb_t = torch.as_tensor(shard.DeviceArray(ptr, (mine, 6)), device=dev)
+        for what in ("positions", "normals", "tangents"):
+            pptr, _ = crowd.device_pointer(what)
+            vert_t.append(torch.as_tensor(shard.DeviceArray(pptr, (mine, V * 3)), device=dev))
 
-    def step():
+    def step(gather=True):
         crowd.evaluate(abi.STAGE_ALL)
-        if world > 1:
+        if launched and gather:
             ctx.synchronize()  # the library's stream -> torch's stream hand-off
             shard.all_gather_rows(aabb_t, total, world)
-            if pos_t is not None:
-                shard.all_gather_rows(pos_t, total, world)
 
     def fence():
         ctx.synchronize()
-        if world > 1:
+        if launched:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if not launched:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     for _ in range(args.warmup):
         step()
@@ -195,11 +238,31 @@ def main():
         step()
         stage[k] = crowd.stage_ms()  # HIP events on the library's stream, around each kernel
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
+
+    # next to the frame (kernels + bounds all-gather = `value`), the kernels alone and the
+    # frame with the skinned vertex buffers gathered as well (xGMI-bound by construction)
+    exchange = None
+    if launched:
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(gather=False)
+        fence()
+        dt_k = max_over_ranks(time.perf_counter() - t0)
+        exchange = {"kernels_only_ms": dt_k / args.steps * 1e3, "with_aabb_allgather_ms": dt / args.steps * 1e3,
+                    "with_vertex_allgather_ms": None}
+        if not args.no_vertex_gather:
+            fence()
+            t0 = time.perf_counter()
+            step()
+            ctx.synchronize()
+            moved = shard.all_gather_rows_chunked(vert_t, total, world)
+            fence()
+            dt_v = max_over_ranks(time.perf_counter() - t0)
+            exchange["with_vertex_allgather_ms"] = dt_v * 1e3
+            exchange["vertex_allgather"] = {"bytes_received_per_rank": moved, "steps": 1,
+                                            "how": "position, normal, tangent one after the other, row chunks through one 8 GiB buffer"}
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -217,25 +280,27 @@ def main():
         info = rig.info
         out = {
             "metric": "skinned vertices/sec (whole node) + ms/frame at N avatars; % HBM roofline",
-            "value": value, "unit": "skinned vertices/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak" if weak else "strong",
+            "value": value, "unit": "skinned vertices/s", "n_gpus": n_gpus, "rccl_ranks": rccl_ranks if launched else 0,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{name}: VRM-shaped avatar x instances" if name in ("c3", "c4") else name,
                        "instances_total": total, "instances_per_gpu": mine, "vertices": V,
                        "joints": rig_data.joint_count, "nodes": rig_data.node_count, "weight_sets": rig_data.set_count,
                        "morph_targets": rig_data.target_count, "channels": rig_data.max_channels,
-                       "stages": "pose+morph+skin+aabb" + ("+allgather(aabb)" if world > 1 else "") +
-                                 ("+allgather(positions)" if args.gather_vertices and world > 1 else ""),
+                       "stages": "pose+morph+skin+aabb" + ("+allgather(aabb)" if launched else ""),
                        "exact_arithmetic": int(info.exact_arithmetic), "exact_arithmetic_config": args.exact, "parallelism": f"instances sharded x{n_gpus}"},
             "stage_ms": {"pose": float(stage[:, 0].mean()), "skin_morph": skin_ms,
                          "aabb_reduce": float(stage[:, 2].mean()), "device_span": float(stage[:, 3].mean())},
-            "roofline": {"bound": "hbm", "kernel": "skin stage = k_skin2 + k_skin_fix (morph + linear-blend skinning + per-tile bounds)", "achieved": achieved / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "skin stage = k_classify + k_skin2 (morph + linear-blend skinning + per-tile bounds)", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": skin_ms, "traffic": traffic},
             "output_placement": crowd.placement,
             "rig_compile": {"tiles": info.tile_count, "max_tile_joints": info.max_tile_joints,
                             "lds_tiles": info.lds_tiles, "morph_entries": int(info.morph_entries)},
         }
+        if exchange is not None:
+            out["exchange"] = exchange
         try:
             if n_gpus != 1:
                 raise RuntimeError("measured at N=1 only")
@@ -251,7 +316,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     crowd.close(); rig.close(); ctx.close()
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SKINRT_ABI_VERSION 2
+#define SKINRT_ABI_VERSION 3
 #define SKINRT_API __attribute__((visibility("default")))
 
 /* ---- error codes ---------------------------------------------------------------- */
@@ -49,6 +49,10 @@ extern "C" {
 #define SKINRT_PATH_TRANSLATION 0
 #define SKINRT_PATH_ROTATION 1
 #define SKINRT_PATH_SCALE 2
+/* glTF "weights" (gltf Property::MorphTargetWeights): the reference's loader stops at todo!()
+ * (renderer-asset/src/loader/gltf/mod.rs:1312); here the channel is sampled with the same rules as the others
+ * (a2-a4, component by component) into the instance's morph weights — see skinrt_channel_desc. */
+#define SKINRT_PATH_WEIGHTS 3
 /* AnimationKeyFrames::{Linear,Step,CubicSpline} — renderer-asset/src/animation.rs:15-20 */
 #define SKINRT_INTERP_LINEAR 0
 #define SKINRT_INTERP_STEP 1
@@ -120,9 +124,14 @@ typedef struct skinrt_channel_desc {
     uint16_t reserved;
     uint32_t key_count;      /* >= 1 */
     const float* times;      /* [key_count], non-decreasing */
-    /* width w = 4 for rotation (x,y,z,w) else 3.
+    /* width w = 4 for rotation (x,y,z,w), 3 for translation / scale, the rig's target_count for weights.
      * LINEAR/STEP: [key_count][w].  CUBICSPLINE: [key_count][3][w] = (in, value, out),
-     * the order of AnimationKeyFrames::CubicSpline (animation.rs:18-19). */
+     * the order of AnimationKeyFrames::CubicSpline (animation.rs:18-19).
+     * SKINRT_PATH_WEIGHTS: at most one such channel per clip (the rig has one morphed mesh; target_node names
+     * its node and is otherwise unused: the channel does not turn a Matrix node into TRS form).  An instance
+     * playing a clip with a weights channel takes its morph weights w[M] from the channel's sample at tau, in
+     * place of skinrt_set_morph_weights / the rig's defaults, which keep applying to every other instance.
+     * The sampled weights are produced by SKINRT_STAGE_POSE and consumed by SKINRT_STAGE_SKIN. */
     const float* values;
 } skinrt_channel_desc;
 
@@ -195,6 +204,8 @@ typedef struct skinrt_rig_info {
     uint64_t device_bytes;         /* bytes of device memory the rig occupies */
     uint32_t exact_arithmetic;     /* 1: the skin stage runs contraction-free on this rig (skinrt_config.exact_arithmetic) */
     float bind_extent;             /* largest |translation component| over the inverse bind matrices */
+    uint32_t weight_channel_clips; /* clips that carry a SKINRT_PATH_WEIGHTS channel */
+    uint32_t reserved;
 } skinrt_rig_info;
 
 /* What skinrt_create_crowd did with the output arrays and what it measured (all zero for small crowds
@@ -300,6 +311,19 @@ SKINRT_API int skinrt_export_skin_uniform(skinrt_crowd* crowd, uint32_t instance
  * tex_coords (2 f32) are copied from `attr` ([V][4] or [V][2], NULL = zeros). dst: V*stride bytes. */
 SKINRT_API int skinrt_export_interleaved(skinrt_crowd* crowd, uint32_t instance, uint32_t layout,
                               const float* attr, void* dst);
+
+/* ---- reference-layout exports on the device (whole instance ranges, device destinations) ------ */
+/* The two exports above for instances [first, first + count) in ONE kernel each, written straight from the
+ * crowd's output arrays to device memory the caller owns (what a render core would bind as vertex / uniform
+ * buffers: VertexBuffer::new, buffer/vertex.rs:110-121; SkinUniformBuffer::update, uniform/skin.rs:59-71).
+ * Asynchronous on the ctx stream, ordered after earlier skinrt_evaluate calls; dev_dst must be 16-byte
+ * aligned.  Bytes are identical to `count` calls of the host exports.
+ *   skin uniform: dev_dst receives count * 128 SkinMatrix = count * 14336 bytes; requires J <= 128.
+ *   interleaved : dev_dst receives count * V records of 76 / 68 bytes, instance after instance with no
+ *                 padding; dev_attr is a DEVICE array [V][4] (color) or [V][2] (tex_coords), NULL = zeros. */
+SKINRT_API int skinrt_export_skin_uniform_device(skinrt_crowd* crowd, uint32_t first, uint32_t count, void* dev_dst);
+SKINRT_API int skinrt_export_interleaved_device(skinrt_crowd* crowd, uint32_t first, uint32_t count, uint32_t layout,
+                                     const float* dev_attr, void* dev_dst);
 
 /* ---- load-time geometry ------------------------------------------------ */
 /* calculate_tangent (renderer-asset/src/tangent.rs:15-58) on the device: per-vertex sum of the unit

@@ -111,6 +111,32 @@ static uint32_t sample_channel(const skinrt_channel_desc* ch, real tau, int quir
     return k;
 }
 
+/* glTF "weights" channel (SKINRT_PATH_WEIGHTS) at tau -> out[M].  The reference's loader stops at todo!() for
+ * Property::MorphTargetWeights (loader/gltf/mod.rs:1312), so there is nothing to restate: the rule is the one the
+ * other channels follow — same key search (a4), Interpolate::linear / cubic_spline (animation.rs:51-63) applied to
+ * each of the M components (the trait is component-wise for every T it is used with), values laid out
+ * [key][M] or [key][in, value, out][M]. */
+ORC_API uint32_t orc_sample_weights(const skinrt_channel_desc* ch, uint32_t M, real tau, int quirk, real* out) {
+    real u; int clamped;
+    uint32_t k = orc_find_key(ch->times, ch->key_count, tau, &u, &clamped);
+    const float* v = ch->values;
+    for (uint32_t m = 0; m < M; ++m) {
+        if (ch->interpolation == SKINRT_INTERP_CUBICSPLINE) {
+            if (clamped) { out[m] = (real)v[((size_t)k * 3 + 1) * M + m]; continue; }
+            real a = (real)v[((size_t)k * 3 + 1) * M + m], b = (real)v[((size_t)k * 3 + 2) * M + m];
+            real c = (real)v[((size_t)(k + 1) * 3 + 1) * M + m], d = (real)v[((size_t)(k + 1) * 3 + 0) * M + m];
+            real td = (real)ch->times[k + 1] - (real)ch->times[k];
+            orc_cubic_spline(&a, &b, &c, &d, u, td, 1, quirk, &out[m]);
+        } else if (clamped || ch->interpolation == SKINRT_INTERP_STEP) {
+            out[m] = (real)v[(size_t)k * M + m];
+        } else {
+            real a = (real)v[(size_t)k * M + m], b = (real)v[(size_t)(k + 1) * M + m];
+            orc_linear(&a, &b, u, 1, &out[m]);
+        }
+    }
+    return k;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* glam Mat4 helpers; m[c*4+r] column-major (Mat4::to_cols_array).                        */
 
@@ -414,7 +440,8 @@ ORC_API int orc_evaluate(const skinrt_rig_desc* rig, const orc_crowd_in* in, con
     real* world = (real*)malloc((size_t)(N ? N : 1) * 16 * sizeof(real));
     real* pal = (real*)malloc((size_t)(J ? J : 1) * 28 * sizeof(real));
     real* mw = (real*)malloc((size_t)(M ? M : 1) * sizeof(real));
-    if (!trs || !is_trs || !world || !pal || !mw) return SKINRT_E_NOMEM;
+    real* mw_anim = (real*)malloc((size_t)(M ? M : 1) * sizeof(real));
+    if (!trs || !is_trs || !world || !pal || !mw || !mw_anim) return SKINRT_E_NOMEM;
 
     for (uint32_t i = begin; i < end; ++i) {
         /* -- a6: local transform selection ------------------------------------------- */
@@ -425,6 +452,7 @@ ORC_API int orc_evaluate(const skinrt_rig_desc* rig, const orc_crowd_in* in, con
             for (int e = 0; e < 3; ++e) trs[n * 10 + 7 + e] = (real)rig->scale[n * 3 + e];
         }
         uint32_t clip = in->clip_id ? in->clip_id[i] : 0;
+        int have_anim_weights = 0;
         if (out->key_index)
             for (uint32_t c = 0; c < Cmax; ++c) out->key_index[(size_t)i * Cmax + c] = UINT32_MAX;
         if (clip != UINT32_MAX && clip < rig->clip_count) {
@@ -433,6 +461,12 @@ ORC_API int orc_evaluate(const skinrt_rig_desc* rig, const orc_crowd_in* in, con
             for (uint32_t c = 0; c < cl->channel_count; ++c) {
                 const skinrt_channel_desc* ch = &cl->channels[c];
                 uint32_t n = ch->target_node;
+                if (ch->path == SKINRT_PATH_WEIGHTS) { /* morph weights, not the node's transform */
+                    uint32_t kw = orc_sample_weights(ch, M, tau, (int)in->cubic_quirk, mw_anim);
+                    if (out->key_index) out->key_index[(size_t)i * Cmax + c] = kw;
+                    have_anim_weights = 1;
+                    continue;
+                }
                 if (!is_trs[n]) { /* Matrix node that is animated: decompose once (node.rs:76-82) */
                     real m[16];
                     for (int e = 0; e < 16; ++e) m[e] = (real)rig->matrix[n * 16 + e];
@@ -476,7 +510,8 @@ ORC_API int orc_evaluate(const skinrt_rig_desc* rig, const orc_crowd_in* in, con
         if (!out->position && !out->normal && !out->tangent && !out->aabb) continue;
         /* -- a13: morph weights: node override, else mesh default, else 0 ------------- */
         for (uint32_t m = 0; m < M; ++m)
-            mw[m] = in->morph_weights ? (real)in->morph_weights[(size_t)i * M + m]
+            mw[m] = have_anim_weights ? mw_anim[m]  /* the clip's weights channel overrides (skinrt.h) */
+                  : in->morph_weights ? (real)in->morph_weights[(size_t)i * M + m]
                                       : (rig->default_weights ? (real)rig->default_weights[m] : (real)0.0);
         real lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         /* cursors into compacted targets (indices strictly increasing) */
@@ -516,6 +551,6 @@ ORC_API int orc_evaluate(const skinrt_rig_desc* rig, const orc_crowd_in* in, con
         free(cur);
         if (out->aabb) for (int e = 0; e < 3; ++e) { out->aabb[(size_t)i * 6 + e] = lo[e]; out->aabb[(size_t)i * 6 + 3 + e] = hi[e]; }
     }
-    free(trs); free(is_trs); free(world); free(pal); free(mw);
+    free(trs); free(is_trs); free(world); free(pal); free(mw); free(mw_anim);
     return SKINRT_OK;
 }

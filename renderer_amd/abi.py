@@ -12,7 +12,7 @@ from typing import List, Optional
 
 import numpy as np
 
-PATH_TRANSLATION, PATH_ROTATION, PATH_SCALE = 0, 1, 2
+PATH_TRANSLATION, PATH_ROTATION, PATH_SCALE, PATH_WEIGHTS = 0, 1, 2, 3
 INTERP_LINEAR, INTERP_STEP, INTERP_CUBICSPLINE = 0, 1, 2
 STAGE_POSE, STAGE_SKIN, STAGE_AABB, STAGE_ALL = 1, 2, 4, 7
 LAYOUT_COLOR_SKIN, LAYOUT_TEXTURE_SKIN = 0, 1
@@ -116,6 +116,7 @@ class RigInfo(C.Structure):
         ("max_tile_joints", C.c_uint32), ("lds_tiles", C.c_uint32), ("max_channels", C.c_uint32),
         ("morph_entries", C.c_uint64), ("device_bytes", C.c_uint64),
         ("exact_arithmetic", C.c_uint32), ("bind_extent", C.c_float),
+        ("weight_channel_clips", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 

@@ -33,7 +33,7 @@ EXPORTS = [
     "skinrt_get_positions", "skinrt_get_normals", "skinrt_get_tangents", "skinrt_get_aabbs",
     "skinrt_get_palette", "skinrt_get_world", "skinrt_get_keyframe_index", "skinrt_download",
     "skinrt_export_skin_uniform", "skinrt_export_interleaved", "skinrt_calculate_tangent",
-    "skinrt_calculate_tangent_noalloc",
+    "skinrt_calculate_tangent_noalloc", "skinrt_export_skin_uniform_device", "skinrt_export_interleaved_device",
 ]
 
 
@@ -79,6 +79,8 @@ def load_library() -> C.CDLL:
         "skinrt_download": [vp, vp, vp, C.c_uint64],
         "skinrt_export_skin_uniform": [vp, C.c_uint32, vp],
         "skinrt_export_interleaved": [vp, C.c_uint32, C.c_uint32, vp, vp],
+        "skinrt_export_skin_uniform_device": [vp, C.c_uint32, C.c_uint32, vp],
+        "skinrt_export_interleaved_device": [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp],
         "skinrt_calculate_tangent": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(C.c_float)],
         "skinrt_calculate_tangent_noalloc": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp],
     }
@@ -307,6 +309,15 @@ class Crowd:
             ap = attr.ctypes.data_as(C.c_void_p)
         _check(self.ctx.lib.skinrt_export_interleaved(self.handle, instance, layout, ap, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def skin_uniform_device(self, first: int, count: int, dev_dst: int):
+        """[count][128] SkinMatrix written by one kernel into device memory at `dev_dst` (asynchronous)."""
+        _check(self.ctx.lib.skinrt_export_skin_uniform_device(self.handle, first, count, C.c_void_p(dev_dst)))
+
+    def interleaved_device(self, first: int, count: int, layout: int, dev_attr: int, dev_dst: int):
+        """[count][V] ColorSkinVertex / TextureSkinVertex records written by one kernel into device memory (asynchronous)."""
+        _check(self.ctx.lib.skinrt_export_interleaved_device(self.handle, first, count, layout,
+                                                             C.c_void_p(dev_attr) if dev_attr else None, C.c_void_p(dev_dst)))
 
     def close(self):
         if self.handle:

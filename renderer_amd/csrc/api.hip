@@ -55,6 +55,7 @@ struct DevBuf {
 struct skinrt_ctx {
     skinrt_config cfg{};
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;  // k_skin_fix next to k_skin2 (launch_skin)
 };
 
 struct skinrt_rig {
@@ -64,29 +65,34 @@ struct skinrt_rig {
     std::vector<DevBuf> bufs;
     uint64_t device_bytes = 0;
     DevBuf default_mw;
+    const uint32_t* joints0_dev = nullptr;  // [V][2] (four u16), for the interleaved export
+    const float* weights0_dev = nullptr;    // [V][4]
 };
 
 struct skinrt_crowd {
     skinrt_ctx* ctx = nullptr;
     skinrt_rig* rig = nullptr;
     uint32_t I = 0;
-    DevBuf tau, clip, mw, root, world, palette, keyidx, pos, nrm, tan, aabb_part, aabb, fix;
+    DevBuf tau, clip, mw, mw_eff, root, world, palette, keyidx, pos, nrm, tan, aabb_part, aabb, fix, amask;
     bool has_root = false;
     SkinPlan plan{};
     PosePath pose_path = kPoseWave;
     skinrt_placement_info place{};
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0-3 stage stamps, 4-5 fork / join of the side stream
     uint32_t last_mask = 0;
     CrowdDev dev() const {
         CrowdDev c{};
         c.I = I;
-        c.tau = tau.as<float>(); c.clip = clip.as<uint32_t>(); c.mw = mw.as<float>();
+        c.tau = tau.as<float>(); c.clip = clip.as<uint32_t>();
+        c.mw_in = mw.as<float>();
+        c.mw = mw_eff.p ? mw_eff.as<float>() : mw.as<float>();  // rigs with weights channels: what the pose stage sampled
         c.root = has_root ? root.as<float>() : nullptr;
         c.world = world.as<float>(); c.palette = palette.as<float>(); c.keyidx = keyidx.as<uint32_t>();
         c.pos = pos.as<float>(); c.nrm = nrm.as<float>(); c.tan = tan.as<float>();
         c.aabb_part = aabb_part.as<float>(); c.aabb = aabb.as<float>();
         c.fix = fix.p ? fix.as<uint32_t>() : nullptr;
         c.fix_inst = fix.p ? fix.as<uint32_t>() + (rig->host.T + 3) / 4 * 4 : nullptr;
+        c.amask = amask.p ? amask.as<uint64_t>() : nullptr;
         return c;
     }
 };
@@ -228,6 +234,21 @@ int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx) {
         delete ctx;
         return fail(SKINRT_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
+    {
+        const char* ev = std::getenv("SKINRT_FIX_STREAM");  // 0: the skin stage's kernels one after the other (measurement)
+        if (!ev || std::atoi(ev) != 0) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent (largest number)
+            const char* pv = std::getenv("SKINRT_FIX_PRIO");
+            const int want = pv ? std::atoi(pv) : 1;  // -1 urgent, 0 default, 1 least urgent (default: it only fills what k_skin2 leaves free)
+            e = hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, want < 0 ? hi : (want > 0 ? lo : (lo + hi) / 2));
+            if (e != hipSuccess) {
+                (void)hipStreamDestroy(ctx->stream);
+                delete ctx;
+                return fail(SKINRT_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+            }
+        }
+    }
     *out_ctx = ctx;
     return SKINRT_OK;
 }
@@ -238,6 +259,10 @@ int skinrt_destroy_ctx(skinrt_ctx* ctx) {
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
+    }
+    if (ctx->side) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipStreamDestroy(ctx->side);
     }
     delete ctx;
     return SKINRT_OK;
@@ -282,14 +307,21 @@ int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig**
     RigDev& d = r->dev;
     d.N = h.N; d.J = h.J; d.V = h.V; d.K = h.K; d.M = h.M; d.clips = h.clips; d.Cmax = h.Cmax;
     d.levels = h.levels; d.T = h.T;
+    d.weight_channel_clips = h.weight_channel_clips;
     const float* defw = nullptr;
 #define UP(field) if ((rc = upload(r, h.field, &d.field)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
     UP(parent) UP(rest_trs) UP(rest_mat) UP(node_matrix) UP(level_start) UP(level_nodes) UP(node_chan)
-    UP(chans) UP(clip_chan_count) UP(times) UP(values) UP(joint_node) UP(ibm) UP(base) UP(wts) UP(lidx)
+    UP(chans) UP(clip_chan_count) UP(clip_weights_chan) UP(times) UP(values) UP(joint_node) UP(ibm) UP(base) UP(wts) UP(lidx)
     UP(tile_joint_start) UP(tile_joints) UP(tile_lds) UP(tile_pair_start) UP(pairs) UP(mblock)
 #undef UP
     if ((rc = upload(r, h.default_weights, &defw)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
     r->default_mw = r->bufs.back();
+    {
+        const uint16_t* j0 = nullptr;
+        if ((rc = upload(r, h.joints0, &j0)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
+        r->joints0_dev = reinterpret_cast<const uint32_t*>(j0);
+        if ((rc = upload(r, h.weights0, &r->weights0_dev)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
+    }
     *out_rig = r;
     return SKINRT_OK;
 }
@@ -309,8 +341,8 @@ int skinrt_destroy_crowd(skinrt_crowd* c) {
         (void)hipSetDevice(c->ctx->cfg.device);
         (void)hipStreamSynchronize(c->ctx->stream);
     }
-    for (DevBuf* b : {&c->tau, &c->clip, &c->mw, &c->root, &c->world, &c->palette, &c->keyidx, &c->pos, &c->nrm,
-                      &c->tan, &c->aabb_part, &c->aabb, &c->fix})
+    for (DevBuf* b : {&c->tau, &c->clip, &c->mw, &c->mw_eff, &c->root, &c->world, &c->palette, &c->keyidx, &c->pos, &c->nrm,
+                      &c->tan, &c->aabb_part, &c->aabb, &c->fix, &c->amask})
         b->release();
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -330,9 +362,11 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
     const size_t I = instances;
     struct { DevBuf* b; size_t n; } plan[] = {
         {&c->tau, I * 4}, {&c->clip, I * 4}, {&c->mw, I * h.M * 4}, {&c->root, I * 48},
+        {&c->mw_eff, h.weight_channel_clips ? I * h.M * 4 : 0},  // morph weights after the weights channels (pose stage)
         {&c->world, I * h.N * 48}, {&c->palette, I * h.J * 96}, {&c->keyidx, I * h.Cmax * 4},
         {&c->aabb_part, I * h.T * 24}, {&c->aabb, I * 24},      // bounds per (instance, tile)
         {&c->fix, h.M ? ((size_t)h.T + 3) / 4 * 16 + I * h.T * 4 : 0},  // per-tile work lists of k_skin_fix
+        {&c->amask, h.M ? I * ((h.M + 63) / 64) * 8 : 0},               // non-zero morph weights as bit rows
     };
     for (auto& it : plan) {
         hipError_t e = it.b->alloc(it.n);
@@ -353,8 +387,9 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
         c->pos.p = p; c->nrm.p = n; c->tan.p = t;
         c->pos.bytes = c->nrm.bytes = c->tan.bytes = out_bytes;
     }
-    for (auto& e : c->ev) {
-        if (hipEventCreate(&e) != hipSuccess) {
+    for (int k = 0; k < 6; ++k) {
+        hipEvent_t& e = c->ev[k];
+        if ((k < 4 ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming)) != hipSuccess) {
             skinrt_destroy_crowd(c);
             return fail(SKINRT_E_DEVICE, "hipEventCreate failed");
         }
@@ -363,6 +398,7 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
     hipError_t e = hipMemsetAsync(c->tau.p, 0, c->tau.bytes, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->clip.p, 0, c->clip.bytes, ctx->stream);
     if (e == hipSuccess && h.M) e = launch_fill_morph_weights(c->mw.as<float>(), rig->default_mw.as<float>(), instances, h.M, ctx->stream);
+    if (e == hipSuccess && c->mw_eff.p) e = launch_fill_morph_weights(c->mw_eff.as<float>(), rig->default_mw.as<float>(), instances, h.M, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         skinrt_destroy_crowd(c);
@@ -446,12 +482,18 @@ int skinrt_evaluate(skinrt_crowd* c, uint32_t mask) {
     const RigDev& rig = c->rig->dev;
     const CrowdDev cr = c->dev();
     HIP_TRY(hipEventRecord(c->ev[0], s));
-    if (mask & SKINRT_STAGE_POSE) HIP_TRY(launch_pose(rig, cr, c->ctx->cfg.cubic_quirk ? 1u : 0u, c->pose_path, s));
+    if (mask & SKINRT_STAGE_POSE) {
+        HIP_TRY(launch_pose(rig, cr, c->ctx->cfg.cubic_quirk ? 1u : 0u, c->pose_path, s));
+        if (c->mw_eff.p) HIP_TRY(launch_sample_weights(rig, cr, c->mw_eff.as<float>(), c->ctx->cfg.cubic_quirk ? 1u : 0u, s));
+    }
     HIP_TRY(hipEventRecord(c->ev[1], s));
     if (mask & SKINRT_STAGE_SKIN) {
         SkinPlan p = c->plan;
         p.aabb = (mask & SKINRT_STAGE_AABB) ? 1 : 0;
-        HIP_TRY(launch_skin(rig, cr, p, s));
+        SkinConcurrency conc{c->ctx->side, c->ev[4], c->ev[5]};
+        if (const char* ov = std::getenv("SKINRT_FIX_ORDER")) conc.skin2_first = (uint32_t)std::atoi(ov);
+        if (const char* bv = std::getenv("SKINRT_FIX_BLOCKS")) conc.fix_blocks = (uint32_t)std::max(1, std::atoi(bv));
+        HIP_TRY(launch_skin(rig, cr, p, s, conc));
     }
     HIP_TRY(hipEventRecord(c->ev[2], s));
     if (mask & SKINRT_STAGE_AABB) HIP_TRY(launch_aabb_reduce(rig, cr, s));
@@ -560,6 +602,32 @@ int skinrt_export_interleaved(skinrt_crowd* c, uint32_t instance, uint32_t layou
         std::memcpy(q, &h.joints0[v * 4], 8); q += 8;
         std::memcpy(q, &h.weights0[v * 4], 16);
     }
+    return SKINRT_OK;
+}
+
+int skinrt_export_skin_uniform_device(skinrt_crowd* c, uint32_t first, uint32_t count, void* dev_dst) {
+    if (int rc = check_crowd(c)) return rc;
+    if (count == 0) return SKINRT_OK;
+    if (!dev_dst) return fail(SKINRT_E_INVALID, "dev_dst is NULL");
+    if (reinterpret_cast<uintptr_t>(dev_dst) & 15u) return fail(SKINRT_E_INVALID, "dev_dst must be 16-byte aligned");
+    if ((uint64_t)first + count > c->I) return fail(SKINRT_E_RANGE, "instance range out of range");
+    // assert!(items.len() <= MAX_JOINTS) — renderer/src/renderer/uniform/skin.rs:40,60
+    if (c->rig->host.J > SKINRT_MAX_JOINTS_REFERENCE) return fail(SKINRT_E_LIMIT, "the reference palette holds at most 128 joints");
+    HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+    HIP_TRY(launch_export_skin_uniform(c->dev(), c->rig->host.J, first, count, dev_dst, c->ctx->stream));
+    return SKINRT_OK;
+}
+
+int skinrt_export_interleaved_device(skinrt_crowd* c, uint32_t first, uint32_t count, uint32_t layout, const float* dev_attr, void* dev_dst) {
+    if (int rc = check_crowd(c)) return rc;
+    if (layout > SKINRT_LAYOUT_TEXTURE_SKIN) return fail(SKINRT_E_INVALID, "unknown vertex layout");
+    if (count == 0) return SKINRT_OK;
+    if (!dev_dst) return fail(SKINRT_E_INVALID, "dev_dst is NULL");
+    if (reinterpret_cast<uintptr_t>(dev_dst) & 15u) return fail(SKINRT_E_INVALID, "dev_dst must be 16-byte aligned");
+    if ((uint64_t)first + count > c->I) return fail(SKINRT_E_RANGE, "instance range out of range");
+    HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+    HIP_TRY(launch_export_interleaved(c->dev(), c->rig->host.V, c->rig->joints0_dev, c->rig->weights0_dev, dev_attr, layout, first, count,
+                                      dev_dst, c->ctx->stream));
     return SKINRT_OK;
 }
 

@@ -20,6 +20,8 @@ struct RigDev {
     const int32_t* node_chan;
     const ChanRec* chans;
     const uint32_t* clip_chan_count;
+    const int32_t* clip_weights_chan;  // [clips] the clip's SKINRT_PATH_WEIGHTS channel, or -1
+    uint32_t weight_channel_clips;     // clips that have one (0: CrowdDev::mw_in is never used)
     const float* times;
     const float* values;
     const uint32_t* joint_node;
@@ -40,7 +42,9 @@ struct CrowdDev {
     uint32_t I;
     const float* tau;      // [I]
     const uint32_t* clip;  // [I]
-    const float* mw;       // [I][M]
+    const float* mw;       // [I][M] morph weights the skin stage uses
+    const float* mw_in;    // [I][M] weights set by the host / rig defaults; differs from mw only for rigs with weights
+                           // channels, where the pose stage writes mw = channel sample or mw_in (k_sample_weights)
     const float* root;     // [I][12] rows, or nullptr
     float* world;          // [I][N][12]
     float* palette;        // [I][J][24]
@@ -55,6 +59,7 @@ struct CrowdDev {
     // fix[tile] = number of instances handed over, fix_inst[tile * I + k] = the k-th of them
     uint32_t* fix;         // [T] counters, or nullptr (rig without morph targets)
     uint32_t* fix_inst;    // [T][I]
+    uint64_t* amask;       // [I][ceil(M / 64)] bit t = morph weight t is non-zero (rebuilt by every skin stage), or nullptr
 };
 
 // How the skinning grid is cut (computed once per crowd by plan_skin()).
@@ -87,13 +92,27 @@ struct SkinPlan {
     uint32_t look2;              // k_skin2: palette LDS-DMA runs this many instances ahead (1 or 2); ring = look2 + 1 slots
 };
 
+// Side stream + fork / join events for the part of the skin stage that runs next to k_skin2 (k_skin_fix);
+// all null: one after the other on the caller's stream.
+struct SkinConcurrency {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    uint32_t skin2_first = 0;     // enqueue k_skin2 before k_skin_fix
+    uint32_t fix_blocks = 32768;  // k_skin_fix grid: about this many blocks
+};
+
 enum PosePath : uint32_t { kPoseWave = 0, kPoseSplit = 1 };
 
 // kernels_pose.hip
 hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t cubic_quirk, PosePath path, hipStream_t s);
+hipError_t launch_sample_weights(const RigDev& rig, const CrowdDev& cr, float* mw_out, uint32_t quirk, hipStream_t s);
 // kernels_skin.hip
-hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s);
+hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s, const SkinConcurrency& conc);
 hipError_t launch_aabb_reduce(const RigDev& rig, const CrowdDev& cr, hipStream_t s);
+// kernels_export.hip: reference-layout records written on the device (instances [first, first + count))
+hipError_t launch_export_interleaved(const CrowdDev& cr, uint32_t V, const uint32_t* joints0, const float* weights0, const float* attr,
+                                     uint32_t layout, uint32_t first, uint32_t count, void* dst, hipStream_t s);
+hipError_t launch_export_skin_uniform(const CrowdDev& cr, uint32_t J, uint32_t first, uint32_t count, void* dst, hipStream_t s);
 // kernels_geom.hip: calculate_tangent on the device (load time)
 size_t tangent_work_bytes(uint32_t vertices, uint32_t corners);
 hipError_t tangent_static_setup(int device);                             // once per device, that device current

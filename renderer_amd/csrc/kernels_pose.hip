@@ -323,7 +323,76 @@ __global__ __launch_bounds__(256) void k_palette(const RigDev rig, const CrowdDe
     palette_entry(w, load_rows(rig.ibm + (size_t)j * 12), cr.palette + g * kPalFloats);
 }
 
+// glTF "weights" channels (SKINRT_PATH_WEIGHTS): thread = (instance, morph target m).  An instance whose clip has
+// such a channel takes weight m from component m of the channel's sample — the rules of sample_channel (a2-a4),
+// one component; every other instance copies the weight the host set.  The reference stops at todo!() here
+// (loader/gltf/mod.rs:1312); the oracle restates this rule (orc_sample_weights).
+__global__ __launch_bounds__(256) void k_sample_weights(const RigDev rig, const CrowdDev cr, float* __restrict__ mw_out, const uint32_t quirk) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (uint64_t)cr.I * rig.M) return;
+    const uint32_t i = (uint32_t)(g / rig.M), m = (uint32_t)(g - (uint64_t)i * rig.M), M = rig.M;
+    const uint32_t clip = cr.clip[i];
+    const int32_t c = clip < rig.clips ? rig.clip_weights_chan[clip] : -1;
+    if (c < 0) { mw_out[g] = cr.mw_in[g]; return; }
+    const ChanRec ch = rig.chans[c];
+    const float* tm = rig.times + ch.time_off;
+    const float* v = rig.values + ch.value_off;
+    const uint32_t n = ch.key_count;
+    const float tau = cr.tau[i];
+    uint32_t k;
+    bool clamped = true;
+    if (n == 1 || tau <= tm[0]) k = 0;
+    else if (tau >= tm[n - 1]) k = n - 1;
+    else {
+        uint32_t lo = 0, hi = n - 1;  // times[lo] <= tau < times[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (tm[mid] <= tau) lo = mid; else hi = mid;
+        }
+        k = lo;
+        clamped = false;
+    }
+    if (m == 0) cr.keyidx[(size_t)i * rig.Cmax + ch.local] = k;
+    float out;
+    if (ch.interp == SKINRT_INTERP_CUBICSPLINE) {
+        if (clamped) out = v[(size_t)(k * 3 + 1) * M + m];
+        else {
+            const float t0 = tm[k], t1 = tm[k + 1];
+            const float u = (tau - t0) / (t1 - t0);
+            const float td = t1 - t0;
+            const float t3 = (u * u) * u;
+            const float t2 = quirk ? t3 : u * u;
+            const float c1 = 2.0f * t3 - 3.0f * t2 + 1.0f;
+            const float c2 = t3 - 2.0f * t2 + u;
+            const float c3 = -2.0f * t3 + 3.0f * t2;
+            const float c4 = t3 - t2;
+            const float vk = v[(size_t)(k * 3 + 1) * M + m], bk = v[(size_t)(k * 3 + 2) * M + m];
+            const float vk1 = v[(size_t)((k + 1) * 3 + 1) * M + m], ak1 = v[(size_t)((k + 1) * 3 + 0) * M + m];
+            const float first = vk * c1;
+            const float second = bk * td * c2;
+            const float third = vk1 * c3;
+            const float forth = ak1 * td * c4;
+            out = first + second + third + forth;
+        }
+    } else if (clamped || ch.interp == SKINRT_INTERP_STEP) {
+        out = v[(size_t)k * M + m];
+    } else {
+        const float t0 = tm[k], t1 = tm[k + 1];
+        const float u = (tau - t0) / (t1 - t0);
+        out = lerp1(v[(size_t)k * M + m], v[(size_t)(k + 1) * M + m], 1.0f - u, u);
+    }
+    mw_out[g] = out;
+}
+
 }  // namespace
+
+hipError_t launch_sample_weights(const RigDev& rig, const CrowdDev& cr, float* mw_out, uint32_t quirk, hipStream_t s) {
+    const uint64_t n = (uint64_t)cr.I * rig.M;
+    if (n == 0) return hipSuccess;
+    if (!mw_out || !cr.mw_in || !rig.clip_weights_chan || (n + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_sample_weights, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, rig, cr, mw_out, quirk);
+    return hipGetLastError();
+}
 
 hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t quirk, PosePath path, hipStream_t s) {
     if (cr.I == 0) return hipSuccess;

@@ -116,8 +116,9 @@ struct GlobalPal {
 
 // Position pass then normal/tangent pass: the two accumulators are never live together and each
 // influence's rows are consumed as they arrive, which keeps the kernel at 4 waves per SIMD.
-// Scalar v_fma_f32 on purpose (the file is built with -fno-slp-vectorize): on gfx950 a
-// v_pk_fma_f32 costs more issue time than the two v_fma_f32 it replaces.
+// Scalar v_fma_f32 on purpose (the file is built with -fno-slp-vectorize).  Measured twice: v_pk_fma_f32 with the
+// weight broadcast by op_sel (no {w, w} pair) needs aligned register pairs for rows and sums — 74 -> 95 VGPRs (K=1),
+// 85 -> 119 (K=2) — and the skin stage got slower: C3 4.68 -> 4.76 ms, C5 10.7 -> 11.5 ms (exact: 12.3 -> 13.5).
 template <bool EXACT, int K, class Pal>
 __device__ __forceinline__ void blend_position(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
                                                float (&S)[12]) {  // rows of the blended 3x4
@@ -726,6 +727,234 @@ __device__ __forceinline__ void wave_minmax6(float& a0, float& a1, float& a2, fl
 #undef SKINRT_DPP_BCAST
 }
 
+
+// Which of a tile's (tile, target) pairs are active for one instance, and whether the self-staging kernel
+// can morph it.  k_skin2 morphs from its two LDS slots only: an instance with 1 or 2 active pairs, both
+// dense, in a tile with at most 32 pairs.  Every other non-idle (tile, instance) is "slow": it goes on the
+// tile's work list (k_classify) and is served by the fix role (fix_role).  k_classify and k_skin2's
+// prologue both call this, so they agree on every (tile, instance).
+struct PairClass {
+    uint32_t mask;            // bit min(q, 31) = pair q has a non-zero weight
+    bool slow;
+    float w_first, w_second;  // weights of the first two active pairs (set for instances that are not slow)
+};
+// `active` = the instance's row of CrowdDev::amask (bit t = morph weight t is non-zero), `words` = its length:
+// the np tests read one or two cached 8-byte words instead of np floats scattered over the instance's weight row.
+__device__ __forceinline__ PairClass classify_pairs(const MorphPair* pairs, uint32_t np, const uint64_t* active, uint32_t words, const float* mwg) {
+    PairClass pc{0u, false, 0.0f, 0.0f};
+    if (np == 0) return pc;  // (rigs without morph targets have no amask at all)
+    uint32_t sparse = 0;
+    const uint64_t a0 = active[0];
+    for (uint32_t q = 0; q < np; ++q) {
+        const MorphPair mp = pairs[q];
+        const uint32_t t = mp.target;
+        const uint64_t wd = words == 1 ? a0 : active[t >> 6];
+        const uint32_t bit = 1u << min(q, 31u);
+        if ((wd >> (t & 63u)) & 1ull) pc.mask |= bit;
+        if (!mp.dense) sparse |= bit;
+    }
+    pc.slow = pc.mask != 0 && (np > 32 || __popc(pc.mask) > 2 || (pc.mask & sparse) != 0);
+    if (SKINRT_ABLATE & 4) { pc.slow = false; pc.mask = 0; }
+    if (pc.mask != 0 && !pc.slow) {  // at most two active pairs, np <= 32: their weights go into the instance's header
+        const uint32_t q1 = (uint32_t)__ffs((int)pc.mask) - 1;
+        pc.w_first = mwg[pairs[q1].target];
+        const uint32_t m2 = pc.mask & (pc.mask - 1);
+        if (m2) pc.w_second = mwg[pairs[(uint32_t)__ffs((int)m2) - 1].target];
+    }
+    return pc;
+}
+
+// amask[i][w] bit t = morph weight 64 w + t of instance i is non-zero: one wave per (instance, word), lanes = targets.
+__global__ __launch_bounds__(256) void k_active_mask(const CrowdDev cr, uint32_t M, uint32_t words) {
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= cr.I * words) return;  // wave-uniform
+    const uint32_t i = g / words, w = g - i * words, t = w * 64 + lane;
+    const float v = t < M ? cr.mw[(size_t)i * M + t] : 0.0f;
+    const uint64_t b = __ballot(v != 0.0f);
+    if (lane == 0) cr.amask[g] = b;
+}
+
+// Work lists of the fix role, built before the skin kernel starts so that both roles can run in ONE launch:
+// thread = (tile, instance); slow pairs are appended to the tile's list (one atomicAdd per wave).
+__global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdDev cr, uint32_t chunks, uint32_t words) {
+    const uint32_t tile = blockIdx.x / chunks, inst = (blockIdx.x - tile * chunks) * 256 + threadIdx.x;
+    if (tile >= rig.T || rig.tile_lds[tile] != 2) return;
+    const uint32_t pbeg = rig.tile_pair_start[tile], np = rig.tile_pair_start[tile + 1] - pbeg;
+    if (np == 0) return;
+    const uint32_t lane = threadIdx.x & 63;
+    bool slow = false;
+    if (inst < cr.I) slow = classify_pairs(rig.pairs + pbeg, np, cr.amask + (size_t)inst * words, words, cr.mw + (size_t)inst * rig.M).slow;
+    const uint64_t bslow = __ballot(slow);
+    if (!bslow) return;  // wave-uniform
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(cr.fix + tile, (uint32_t)__popcll(bslow));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (slow) {
+        const uint32_t e = base + (uint32_t)__popcll(bslow & ((1ull << lane) - 1ull));
+        if (e < cr.I) cr.fix_inst[(size_t)tile * cr.I + e] = inst;  // (an instance is listed at most once per tile)
+    }
+}
+
+// fix_role — the (tile, instance) pairs the self-staging role leaves out (k_classify lists them): instances with three or more active
+// morph pairs in the tile, with a compacted pair, or in a tile with more than 32 pairs.  A block
+// takes kFixChunk consecutive work-list entries (k_skin2 blocks append theirs together, so the
+// tile — and with it the block's vertex data — rarely changes inside a chunk).  Per entry the
+// palette rows of the tile's joints are staged in LDS (at most 126 16-byte pieces), the active
+// pairs' deltas come by plain loads (L2-resident), and resident blocks cover each other's latency.
+// Same arithmetic, in the same order, as the staged kernels (a13: targets ascending).
+constexpr uint32_t kFixChunk = 8;
+constexpr uint32_t kFixLdsBytes = 2 * 128 * 16 + 4 * 6 * 4 + 32 + 64 * sizeof(MorphPair);  // of the block's dynamic LDS
+// fb = this block's index among the kernel's `fix_blocks` blocks (a multiple of 8 * ceil(T / 8))
+template <bool EXACT, int K>
+__device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, float4* smem, uint32_t fb, uint32_t fix_blocks) {
+    constexpr uint32_t TV = kTileVerts;
+    constexpr int W = 4 * K;
+    f4 (*pal_s)[128] = reinterpret_cast<f4 (*)[128]>(smem);                            // [2][128]
+    float (*part)[6] = reinterpret_cast<float (*)[6]>(pal_s + 2);                        // [4][6] (+ 32 B pad)
+    MorphPair* pairs_l = reinterpret_cast<MorphPair*>(reinterpret_cast<char*>(part) + 4 * 6 * 4 + 32);  // the tile's first 64 pair records
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // block -> (tile, chunk lane): consecutive block ids go round-robin to the 8 XCDs; every block of
+    // a tile gets the same id modulo 8 (tile % 8: neighbouring tiles, which tend to be equally busy,
+    // go to different XCDs), so the tile's deltas are fetched into ONE L2
+    const uint32_t tiles_per_xcd = (rig.T + 7) / 8;
+    const uint32_t kb = fb >> 3;
+    const uint32_t tile = (kb % tiles_per_xcd) * 8 + (fb & 7);
+    const uint32_t chunk_lane = kb / tiles_per_xcd, chunk_lanes = fix_blocks / (8 * tiles_per_xcd);
+    if (tile >= rig.T) return;
+    const uint32_t count = min(cr.fix[tile], cr.I);
+    if (chunk_lane * kFixChunk >= count) return;
+    const Outputs out{cr.pos, cr.nrm, cr.tan};
+    const bool normalize = plan.normalize != 0;
+    const uint32_t M = rig.M;
+    const f4* pal_g = reinterpret_cast<const f4*>(cr.palette);
+    // the block's tile: vertex data, joint list, pair records — loaded once
+    const bool valid = tile * TV + tid < rig.V;
+    float p0[3], n0[3], t0[3], w[W];
+    uint32_t li[W];
+    {
+        const float* b = rig.base + (size_t)tile * 9 * TV + tid;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) { p0[x] = b[x * TV]; n0[x] = b[(3 + x) * TV]; t0[x] = b[(6 + x) * TV]; }
+        const float* wt = rig.wts + (size_t)tile * W * TV + tid;
+        const uint16_t* lp = rig.lidx + (size_t)tile * W * TV + tid;
+#pragma unroll
+        for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
+    }
+    const uint32_t jstart = rig.tile_joint_start[tile];
+    const uint32_t npieces = (rig.tile_joint_start[tile + 1] - jstart) * 6;  // <= 126 for k_skin2's tiles
+    const uint32_t joff = tid < npieces ? rig.tile_joints[jstart + tid / 6] * 6 + tid % 6 : 0u;
+    const uint32_t pbeg = rig.tile_pair_start[tile], pend = rig.tile_pair_start[tile + 1];
+    if (tid < min(pend - pbeg, 64u)) pairs_l[tid] = rig.pairs[pbeg + tid];
+    __syncthreads();
+    const uint32_t* list = cr.fix_inst + (size_t)tile * cr.I;
+    uint32_t flip = 0;  // palette staging buffer in use
+    for (uint32_t e0 = chunk_lane * kFixChunk; e0 < count; e0 += chunk_lanes * kFixChunk) {
+        const uint32_t e1 = min(count, e0 + kFixChunk);
+        // the chunk's instances in one load (lane k = entry e0 + k)
+        uint32_t ents = 0;
+        if (e0 + lane < e1 && lane < kFixChunk) ents = list[e0 + lane];
+        // palette piece and pair weights of the NEXT entry, requested while the current one is worked on
+        f4 piece_next = {0.0f, 0.0f, 0.0f, 0.0f};
+        float mwq_next = 0.0f;
+        bool have_next = false;
+        for (uint32_t e = e0; e < e1; ++e) {
+            const uint32_t inst = __builtin_amdgcn_readlane(ents, e - e0);
+            // stage this instance's palette rows; the buffers alternate, so the one barrier below
+            // also separates the previous entry's reads of this buffer from these writes
+            f4* ps = pal_s[flip];
+            flip ^= 1u;
+            const float* mwg = cr.mw + (size_t)inst * M;
+            // the first 64 pairs: one parallel fetch of their weights (lane q = pair q), then only the
+            // active ones are visited, ascending — not one dependent load chain per pair
+            const uint32_t np64 = min(pend - pbeg, 64u);
+            f4 piece = piece_next;
+            float mwq = mwq_next;
+            if (!have_next) {
+                if (tid < npieces) piece = pal_g[(size_t)inst * rig.J * 6 + joff];
+                mwq = lane < np64 ? mwg[pairs_l[lane].target] : 0.0f;
+            }
+            have_next = e + 1 < e1;
+            if (have_next) {
+                const uint32_t inst2 = __builtin_amdgcn_readlane(ents, (e + 1 - e0) & 63u);
+                if (tid < npieces) piece_next = pal_g[(size_t)inst2 * rig.J * 6 + joff];
+                mwq_next = lane < np64 ? cr.mw[(size_t)inst2 * M + pairs_l[lane].target] : 0.0f;
+            }
+            if (tid < npieces) ps[tid] = piece;
+            float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
+#ifndef SKINRT_FIX_ABLATE
+#define SKINRT_FIX_ABLATE 0
+#endif
+            for (uint64_t act = (SKINRT_FIX_ABLATE & 1) ? 0ull : __ballot(mwq != 0.0f); act; act &= act - 1) {
+                const uint32_t q = (uint32_t)__builtin_ctzll(act);
+                const float mw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mwq), q));
+                const MorphPair mp = pairs_l[q];
+                if (!((mp.wave_mask >> wave) & 1u)) continue;  // nothing of this wave's 64 vertices moves: adds exactly 0
+                const bool dense = mp.dense != 0;
+                morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
+            }
+            for (uint32_t q = pbeg + 64; q < pend; ++q) {
+                const MorphPair mp = rig.pairs[q];
+                const float mw = mwg[mp.target];
+                if (mw == 0.0f || !((mp.wave_mask >> wave) & 1u)) continue;  // wave-uniform; adds exactly 0
+                const bool dense = mp.dense != 0;
+                morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
+            }
+            lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
+            float op[3];
+            skin_store<EXACT, K>(LdsPal{ps}, w, li, p, n, t, normalize, valid && !(SKINRT_FIX_ABLATE & 2), out, (size_t)inst * rig.V * 3,
+                                 (tile * TV + tid) * 12, op);
+            if (plan.aabb) {
+                float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
+                wave_minmax6(a0, a1, a2, b0, b1, b2);
+                if ((tid & 63) == 63) {
+                    float* dst = part[wave];
+                    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = b0; dst[4] = b1; dst[5] = b2;
+                }
+                lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
+                if (tid < 6) {
+                    float r = part[0][tid];
+                    for (int q = 1; q < 4; ++q) r = tid < 3 ? fminf(r, part[q][tid]) : fmaxf(r, part[q][tid]);
+                    cr.aabb_part[((size_t)inst * rig.T + tile) * 6 + tid] = r;
+                }
+                // part[] is next written after the next entry's first barrier
+            }
+        }
+    }
+}
+
+
+// Bounds of a wave's 64 positions in 20 VALU operations instead of wave_minmax6's 42: minima are carried
+// as maxima of the negated value (exact), and the six values are reduced by TRANSPOSE steps — gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange half-waves / rows between two registers, so one swap + one
+// v_max halves TWO values at once.  Result (one register): lanes 8k .. 8k+7 all hold component
+// kBoundsComp[k] of the wave's bounds, k = lane / 8:  +max x, +max z, +max y, +max z, -min x, -min z, -min y, -min z.
+__device__ __forceinline__ float vmax_raw(uint32_t a, uint32_t b) {  // plain v_max_f32: fmaxf() adds a canonicalize per input
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float wave_bounds_packed(const float (&v)[3], bool upper_half_of_row) {
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {  // [max partials of c | max partials of -c], 32 lanes each
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[c]), __float_as_uint(-v[c]), false, false);
+        r[c] = vmax_raw(sw[0], sw[1]);
+    }
+    // rows of 16: r[0] = [x x -x -x], r[1] = [y y -y -y], r[2] = [z z -z -z]
+    const auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[0]), __float_as_uint(r[1]), false, false);
+    float a = vmax_raw(s01[0], s01[1]);  // rows: x, y, -x, -y
+    const auto s22 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[2]), __float_as_uint(r[2]), false, false);
+    float b = vmax_raw(s22[0], s22[1]);  // rows: z, z, -z, -z
+    // halve the rows (lane l with lane l ^ 8), merge the two registers, then finish inside the 8-lane groups
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(a), "+v"(b));
+    float m = upper_half_of_row ? b : a;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(m));
+    return m;
+}
+
 constexpr uint32_t kSkin2Threads = 256;
 
 template <bool EXACT, int K, int LOOK>
@@ -767,12 +996,11 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     const uint32_t np = rig.tile_pair_start[tile + 1] - pbeg;
     const uint32_t jstart = rig.tile_joint_start[tile];
     const uint32_t jcnt = rig.tile_joint_start[tile + 1] - jstart;  // <= 21
-    const bool exact_mask = np <= 32;
 
     // ---------------- block prologue (all 256 threads; no store has been issued yet) ----------------
     for (uint32_t c = tid; c < np; c += kSkin2Threads) pairs_s[c] = rig.pairs[pbeg + c];
     if (plan.aabb)
-        for (uint32_t c = tid; c < kSkin2Range * 6; c += kSkin2Threads) bb_s[c] = (c % 6 < 3) ? __builtin_inff() : -__builtin_inff();
+        for (uint32_t c = tid; c < kSkin2Range * 6; c += kSkin2Threads) bb_s[c] = -__builtin_inff();  // cells hold {-min, +max}: all folded with max
     __syncthreads();
     // pairs that move at least one of THIS wave's 64 vertices (bit q, first 32 pairs): the others are
     // neither requested nor applied by this wave (their deltas here are all zero)
@@ -786,44 +1014,14 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         bool slow = false;
         float w_first = 0.0f, w_second = 0.0f;
         if (tid < nin) {
-            my_mask = 0;
-            uint32_t sparse = 0;
-            const float* mwg = cr.mw + (size_t)(i0 + tid) * M;
-            for (uint32_t q0 = 0; q0 < np; q0 += 4) {  // four weights in flight: one memory round trip per four pairs
-                MorphPair mp[4];
-                float wq[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    mp[u] = pairs_s[min(q0 + u, np - 1)];
-                    wq[u] = mwg[mp[u].target];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (q0 + u >= np) break;
-                    const uint32_t bit = 1u << min(q0 + u, 31u);
-                    if (wq[u] != 0.0f) {
-                        // the first two active pairs' weights go into the instance's header later
-                        if (my_mask == 0) w_first = wq[u]; else if ((my_mask & (my_mask - 1)) == 0) w_second = wq[u];
-                        my_mask |= bit;
-                    }
-                    if (!mp[u].dense) sparse |= bit;
-                }
-            }
-            slow = my_mask != 0 && (!exact_mask || __popc(my_mask) > 2 || (my_mask & sparse) != 0);
-            if (SKINRT_ABLATE & 4) { slow = false; my_mask = 0; }
+            const uint32_t words = (M + 63) / 64;
+            const PairClass pc = classify_pairs(pairs_s, np, cr.amask + (size_t)(i0 + tid) * words, words, cr.mw + (size_t)(i0 + tid) * M);
+            slow = pc.slow;
+            my_mask = slow ? 0xffffffffu : pc.mask;  // slow: on the tile's work list already (k_classify)
+            w_first = pc.w_first;
+            w_second = pc.w_second;
         }
         const uint64_t bslow = __ballot(slow);
-        if (bslow) {  // wave-uniform
-            const uint32_t n = (uint32_t)__popcll(bslow);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(cr.fix + tile, n);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (slow) {
-                const uint32_t e = base + (uint32_t)__popcll(bslow & ((1ull << lane) - 1ull));
-                if (e < cr.I) cr.fix_inst[(size_t)tile * cr.I + e] = i0 + tid;  // (an instance is handed over at most once per tile)
-                my_mask = 0xffffffffu;
-            }
-        }
         if (lane == 0 && wave < 2) cnt_s[4 + wave] = (uint32_t)__popcll(bslow);
         if (tid < kSkin2Range) { mask_s[tid] = my_mask; w12_s[tid] = make_float2(w_first, w_second); }
     }
@@ -929,11 +1127,16 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     const uint32_t wave_valid = __builtin_amdgcn_readfirstlane(__ballot(valid) != 0ull ? 1u : 0u);
     // stores this wave issues per instance: position / normal / tangent (none if the wave holds no
     // real vertex)
-    const uint32_t spi = wave_valid ? 3u : 0u;
+    constexpr uint32_t spi = 3u;
+    // a wave none of whose lanes holds a real vertex (tail of the last tile) stores nothing and its bounds repeat a
+    // real vertex of another wave: it sits the loop out, which makes "3 stores per instance" a constant of the waits
+    const uint32_t nloop = wave_valid ? nproc : 0u;
     const char* pal_g = reinterpret_cast<const char*>(cr.palette);
     const size_t pal_stride = (size_t)rig.J * 96;
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)pal_ring);
     const uint32_t bb_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)bb_s);
+    // the cell component this lane folds into (lanes 8k: see wave_bounds_packed): {-min x,y,z, +max x,y,z} = components 0 .. 5
+    const uint32_t bb_lane = bb_lds + ((0x21205453u >> ((lane >> 3) * 4)) & 7u) * 4;
     auto pal_dma = [&](uint32_t inst, uint32_t slot) {  // request one instance's palette rows into ring slot `slot`
         const char* gbase = pal_g + (size_t)inst * pal_stride;
         const uint32_t lds0 = ring_lds + slot * pal_slot_f * 4;
@@ -965,7 +1168,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     __syncthreads();  // headers visible
 
     // ---------------- per-wave pipeline ----------------
-    for (uint32_t q = 0; q < min(L, nproc); ++q) pal_dma(__builtin_amdgcn_readfirstlane(hdr_s[q].y), q);  // q < L < R
+    for (uint32_t q = 0; q < min(L, nloop); ++q) pal_dma(__builtin_amdgcn_readfirstlane(hdr_s[q].y), q);  // q < L < R
     uint32_t hx, hi, hz, hw;
     {
         const uint4 h0 = hdr_s[0];
@@ -978,8 +1181,9 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     if (runs) morph_dma(z0 ? __builtin_amdgcn_readfirstlane(hdr_s[z0].x) : hx);
     wait_vmcnt<0>();
     bool dma_pending = true;  // "this instance's morph pairs were requested": true for instance 0 (just waited for everything)
-    uint32_t inst_ahead = nproc > L ? __builtin_amdgcn_readfirstlane(hdr_s[L].y) : 0u;  // instance at pos + L
-    for (uint32_t pos = 0; pos < nproc; ++pos) {
+    uint32_t inst_ahead = nloop > L ? __builtin_amdgcn_readfirstlane(hdr_s[L].y) : 0u;  // instance at pos + L
+    uint32_t slot_cur = 0, slot_ahead = L % R;  // ring slots of instance pos and of instance pos + L
+    for (uint32_t pos = 0; pos < nloop; ++pos) {
         const uint32_t i = hi;
         const uint32_t na = (SKINRT_ABLATE & 1) ? 0u : (hx & 0xffu);
         const bool reload = ((hx >> 8) & 1u) != 0;
@@ -989,18 +1193,18 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         // issued at least spi stores; its morph pairs (if they had to be reloaded) were requested
         // before the previous instance's last spi - 1 stores.  First instance: everything has landed.
         if (pos) {
-            if (reload && dma_pending) wait_vmcnt_dyn(spi ? spi - 1 : 0);
-            else wait_vmcnt_dyn(spi * L);
+            if (reload && dma_pending) wait_vmcnt<spi - 1>();
+            else wait_vmcnt<spi * L>();
         }
         // (2) request the palette of instance pos + L, and fetch the instance id after that one
         uint32_t ahead_next = 0;
-        if (pos + L < nproc) {
-            pal_dma(inst_ahead, (pos + L) % R);
-            if (pos + L + 1 < nproc) ahead_next = hdr_s[pos + L + 1].y;
+        if (pos + L < nloop) {
+            pal_dma(inst_ahead, slot_ahead);
+            if (pos + L + 1 < nloop) ahead_next = hdr_s[pos + L + 1].y;
         }
         if ((hx >> 10) & 1u) morph_dma((hx & 0xffff0000u) | ((hx >> 11) & 3u));  // spacer: the next run's pairs
         uint4 hdr_next = make_uint4(0, 0, 0, 0);
-        if (pos + 1 < nproc) hdr_next = hdr_s[pos + 1];
+        if (pos + 1 < nloop) hdr_next = hdr_s[pos + 1];
         // (3) morph (a13): p = p0 + sum_m w_m * delta_m, targets ascending
         float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
         if (na) {
@@ -1011,7 +1215,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         float op[3];
         {
             float S[12];
-            blend_position<EXACT, K>(LdsPal{reinterpret_cast<const f4*>(pal_ring + (pos % R) * pal_slot_f)}, w, li, S);
+            blend_position<EXACT, K>(LdsPal{reinterpret_cast<const f4*>(pal_ring + slot_cur * pal_slot_f)}, w, li, S);
             apply_position<EXACT>(S, p, op);
         }
         if (valid) store3(out.pos + obase, olb, op);
@@ -1029,7 +1233,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         float on[3], ot[3];
         {
             float Nm[9];
-            blend_normal<EXACT, K>(LdsPal{reinterpret_cast<const f4*>(pal_ring + (pos % R) * pal_slot_f)}, w, li, Nm);
+            blend_normal<EXACT, K>(LdsPal{reinterpret_cast<const f4*>(pal_ring + slot_cur * pal_slot_f)}, w, li, Nm);
             apply_normal<EXACT>(Nm, n, t, normalize, on, ot);
         }
         if (valid) {
@@ -1040,18 +1244,14 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         // into the block's cell for this position with LDS atomics: nothing is returned, so nothing
         // waits.  Per-wave records in HBM (two 12-byte stores per wave and instance) cost 0.8-1.2 ms
         // of the C3 frame as scattered partial-line writes.
+        slot_cur = slot_cur + 1 == R ? 0u : slot_cur + 1;
+        slot_ahead = slot_ahead + 1 == R ? 0u : slot_ahead + 1;
         if (plan.aabb) {
-            float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
-            wave_minmax6(a0, a1, a2, b0, b1, b2);
-            uint32_t lid;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lid));
-            if (lid == 63) {
-                // asm: left to the compiler, an LDS atomic on a wave-uniform address is wrapped in a
-                // lane loop that pre-reduces the (here: single) active lane
-                const uint32_t cell = bb_lds + pos * 24;
-                asm volatile("ds_min_f32 %0, %1\n\tds_min_f32 %0, %2 offset:4\n\tds_min_f32 %0, %3 offset:8\n\t"
-                             "ds_max_f32 %0, %4 offset:12\n\tds_max_f32 %0, %5 offset:16\n\tds_max_f32 %0, %6 offset:20"
-                             : : "v"(cell), "v"(a0), "v"(a1), "v"(a2), "v"(b0), "v"(b1), "v"(b2) : "memory");
+            const float m = wave_bounds_packed(op, (lane & 8u) != 0);
+            if ((lane & 7u) == 0) {
+                // asm: left to the compiler, an LDS atomic is wrapped in a lane loop that pre-reduces equal addresses
+                const uint32_t cell = bb_lane + pos * 24;
+                asm volatile("ds_max_f32 %0, %1" : : "v"(cell), "v"(m) : "memory");
             }
         }
     }
@@ -1063,134 +1263,18 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
             const float* cell = bb_s + tid * 6;
             float* dst = cr.aabb_part + ((size_t)hdr_s[tid].y * rig.T + tile) * 6;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) dst[c] = cell[c];
+            for (int c = 0; c < 6; ++c) dst[c] = c < 3 ? -cell[c] : cell[c];
         }
     }
 }
 
-// k_skin_fix — the (tile, instance) pairs k_skin2 left out: instances with three or more active
-// morph pairs in the tile, with a compacted pair, or in a tile with more than 32 pairs.  A block
-// takes kFixChunk consecutive work-list entries (k_skin2 blocks append theirs together, so the
-// tile — and with it the block's vertex data — rarely changes inside a chunk).  Per entry the
-// palette rows of the tile's joints are staged in LDS (at most 126 16-byte pieces), the active
-// pairs' deltas come by plain loads (L2-resident), and resident blocks cover each other's latency.
-// Same arithmetic, in the same order, as the staged kernels (a13: targets ascending).
-constexpr uint32_t kFixChunk = 8;
+// The fix role's kernel.  (Tried: the role inside the k_skin2 launch, its block groups dealt out between the
+// self-staging groups.  Slower — 5.7-6.0 ms against 4.7 on C3: a launch has ONE LDS size, so every fix block takes
+// one of the CU's five 31 KiB block slots from k_skin2; as a kernel of its own it fits into what k_skin2 leaves free.)
 template <bool EXACT, int K>
 __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
-    constexpr uint32_t TV = kTileVerts;
-    constexpr int W = 4 * K;
-    __shared__ f4 pal_s[2][128];
-    __shared__ float part[4][6];
-    __shared__ MorphPair pairs_l[64];  // the tile's first 64 pair records
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // block -> (tile, chunk lane): consecutive block ids go round-robin to the 8 XCDs; every block of
-    // a tile gets the same id modulo 8 (tile % 8: neighbouring tiles, which tend to be equally busy,
-    // go to different XCDs), so the tile's deltas are fetched into ONE L2
-    const uint32_t tiles_per_xcd = (rig.T + 7) / 8;
-    const uint32_t kb = blockIdx.x >> 3;
-    const uint32_t tile = (kb % tiles_per_xcd) * 8 + (blockIdx.x & 7);
-    const uint32_t chunk_lane = kb / tiles_per_xcd, chunk_lanes = gridDim.x / (8 * tiles_per_xcd);
-    if (tile >= rig.T) return;
-    const uint32_t count = min(cr.fix[tile], cr.I);
-    if (chunk_lane * kFixChunk >= count) return;
-    const Outputs out{cr.pos, cr.nrm, cr.tan};
-    const bool normalize = plan.normalize != 0;
-    const uint32_t M = rig.M;
-    const f4* pal_g = reinterpret_cast<const f4*>(cr.palette);
-    // the block's tile: vertex data, joint list, pair records — loaded once
-    const bool valid = tile * TV + tid < rig.V;
-    float p0[3], n0[3], t0[3], w[W];
-    uint32_t li[W];
-    {
-        const float* b = rig.base + (size_t)tile * 9 * TV + tid;
-#pragma unroll
-        for (int x = 0; x < 3; ++x) { p0[x] = b[x * TV]; n0[x] = b[(3 + x) * TV]; t0[x] = b[(6 + x) * TV]; }
-        const float* wt = rig.wts + (size_t)tile * W * TV + tid;
-        const uint16_t* lp = rig.lidx + (size_t)tile * W * TV + tid;
-#pragma unroll
-        for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
-    }
-    const uint32_t jstart = rig.tile_joint_start[tile];
-    const uint32_t npieces = (rig.tile_joint_start[tile + 1] - jstart) * 6;  // <= 126 for k_skin2's tiles
-    const uint32_t joff = tid < npieces ? rig.tile_joints[jstart + tid / 6] * 6 + tid % 6 : 0u;
-    const uint32_t pbeg = rig.tile_pair_start[tile], pend = rig.tile_pair_start[tile + 1];
-    if (tid < min(pend - pbeg, 64u)) pairs_l[tid] = rig.pairs[pbeg + tid];
-    __syncthreads();
-    const uint32_t* list = cr.fix_inst + (size_t)tile * cr.I;
-    uint32_t flip = 0;  // palette staging buffer in use
-    for (uint32_t e0 = chunk_lane * kFixChunk; e0 < count; e0 += chunk_lanes * kFixChunk) {
-        const uint32_t e1 = min(count, e0 + kFixChunk);
-        // the chunk's instances in one load (lane k = entry e0 + k)
-        uint32_t ents = 0;
-        if (e0 + lane < e1 && lane < kFixChunk) ents = list[e0 + lane];
-        // palette piece and pair weights of the NEXT entry, requested while the current one is worked on
-        f4 piece_next = {0.0f, 0.0f, 0.0f, 0.0f};
-        float mwq_next = 0.0f;
-        bool have_next = false;
-        for (uint32_t e = e0; e < e1; ++e) {
-            const uint32_t inst = __builtin_amdgcn_readlane(ents, e - e0);
-            // stage this instance's palette rows; the buffers alternate, so the one barrier below
-            // also separates the previous entry's reads of this buffer from these writes
-            f4* ps = pal_s[flip];
-            flip ^= 1u;
-            const float* mwg = cr.mw + (size_t)inst * M;
-            // the first 64 pairs: one parallel fetch of their weights (lane q = pair q), then only the
-            // active ones are visited, ascending — not one dependent load chain per pair
-            const uint32_t np64 = min(pend - pbeg, 64u);
-            f4 piece = piece_next;
-            float mwq = mwq_next;
-            if (!have_next) {
-                if (tid < npieces) piece = pal_g[(size_t)inst * rig.J * 6 + joff];
-                mwq = lane < np64 ? mwg[pairs_l[lane].target] : 0.0f;
-            }
-            have_next = e + 1 < e1;
-            if (have_next) {
-                const uint32_t inst2 = __builtin_amdgcn_readlane(ents, (e + 1 - e0) & 63u);
-                if (tid < npieces) piece_next = pal_g[(size_t)inst2 * rig.J * 6 + joff];
-                mwq_next = lane < np64 ? cr.mw[(size_t)inst2 * M + pairs_l[lane].target] : 0.0f;
-            }
-            if (tid < npieces) ps[tid] = piece;
-            float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
-#ifndef SKINRT_FIX_ABLATE
-#define SKINRT_FIX_ABLATE 0
-#endif
-            for (uint64_t act = (SKINRT_FIX_ABLATE & 1) ? 0ull : __ballot(mwq != 0.0f); act; act &= act - 1) {
-                const uint32_t q = (uint32_t)__builtin_ctzll(act);
-                const float mw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mwq), q));
-                const MorphPair mp = pairs_l[q];
-                if (!((mp.wave_mask >> wave) & 1u)) continue;  // nothing of this wave's 64 vertices moves: adds exactly 0
-                const bool dense = mp.dense != 0;
-                morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
-            }
-            for (uint32_t q = pbeg + 64; q < pend; ++q) {
-                const MorphPair mp = rig.pairs[q];
-                const float mw = mwg[mp.target];
-                if (mw == 0.0f || !((mp.wave_mask >> wave) & 1u)) continue;  // wave-uniform; adds exactly 0
-                const bool dense = mp.dense != 0;
-                morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
-            }
-            lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
-            float op[3];
-            skin_store<EXACT, K>(LdsPal{ps}, w, li, p, n, t, normalize, valid && !(SKINRT_FIX_ABLATE & 2), out, (size_t)inst * rig.V * 3,
-                                 (tile * TV + tid) * 12, op);
-            if (plan.aabb) {
-                float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
-                wave_minmax6(a0, a1, a2, b0, b1, b2);
-                if ((tid & 63) == 63) {
-                    float* dst = part[wave];
-                    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = b0; dst[4] = b1; dst[5] = b2;
-                }
-                lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
-                if (tid < 6) {
-                    float r = part[0][tid];
-                    for (int q = 1; q < 4; ++q) r = tid < 3 ? fminf(r, part[q][tid]) : fmaxf(r, part[q][tid]);
-                    cr.aabb_part[((size_t)inst * rig.T + tile) * 6 + tid] = r;
-                }
-                // part[] is next written after the next entry's first barrier
-            }
-        }
-    }
+    extern __shared__ float4 smem[];
+    fix_role<EXACT, K>(rig, cr, plan, smem, blockIdx.x, gridDim.x);
 }
 
 // a14: bounds of one instance = min/max over its tiles' partial bounds (order-independent, exact).
@@ -1232,7 +1316,7 @@ hipError_t launch_skin_k(const RigDev& rig, const CrowdDev& cr, const SkinPlan& 
 
 }  // namespace
 
-hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s) {
+hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s, const SkinConcurrency& conc) {
     if (cr.I == 0 || rig.T == 0) return hipSuccess;
     // what the kernel's indexing assumes about the plan (checked here, on the host, every launch)
     if (plan.batch == 0 || plan.range == 0 || plan.range > 256 || plan.range % plan.batch != 0 ||
@@ -1248,10 +1332,48 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
     hipError_t e = hipSuccess;
     // tiles of kind 2 (short joint lists): the self-staging kernel unless it is switched off
     if (plan.v2 && (plan.kinds & 4u)) {
+        // Work lists first (k_classify), then the two consumers at the same time: k_skin_fix (latency-bound, few
+        // stores, 5 KiB of LDS) on the side stream fits into the wave slots, registers and LDS that k_skin2's five
+        // blocks per CU leave free, so it costs the stage almost nothing; one after the other it costs its full
+        // 0.5 ms (C3).  Fork / join by events: the caller's stream sees the stage as one unit.
+        const bool side = cr.fix && conc.side != nullptr && conc.fork != nullptr && conc.join != nullptr;
         if (cr.fix) {
             e = hipMemsetAsync(cr.fix, 0, (size_t)rig.T * 4, s);  // empty work lists
             if (e != hipSuccess) return e;
+            const uint32_t chunks = (cr.I + 255) / 256;
+            if ((uint64_t)rig.T * chunks > 0x7fffffffull) return hipErrorInvalidValue;
+            const uint32_t words = (rig.M + 63) / 64;
+            if (!cr.amask || (uint64_t)cr.I * words > 0x7fffffffull) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(k_active_mask, dim3((cr.I * words + 3) / 4), dim3(256), 0, s, cr, rig.M, words);
+            hipLaunchKernelGGL(k_classify, dim3(rig.T * chunks), dim3(256), 0, s, rig, cr, chunks, words);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            if (side && (e = hipEventRecord(conc.fork, s)) != hipSuccess) return e;  // the lists are complete here
         }
+        auto launch_fix = [&]() -> hipError_t {
+            hipStream_t fs = s;
+            hipError_t fe;
+            if (side) {
+                if ((fe = hipStreamWaitEvent(conc.side, conc.fork, 0)) != hipSuccess) return fe;
+                fs = conc.side;
+            }
+            // one block per (tile, chunk lane).  Lists are uneven (tiles with many pairs hand over most), so there are
+            // enough lanes that the longest list is a few chunks per block; blocks past a list's end leave at once
+            const uint32_t lanes = std::min((cr.I + kFixChunk - 1) / kFixChunk, std::max(1u, conc.fix_blocks / rig.T));
+            const dim3 fgrid(8u * ((rig.T + 7) / 8) * lanes), fblock(256);
+            if (rig.K == 1) {
+                if (plan.exact) hipLaunchKernelGGL((k_skin_fix<true, 1>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan);
+                else hipLaunchKernelGGL((k_skin_fix<false, 1>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan);
+            } else {
+                if (plan.exact) hipLaunchKernelGGL((k_skin_fix<true, 2>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan);
+                else hipLaunchKernelGGL((k_skin_fix<false, 2>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan);
+            }
+            if ((fe = hipGetLastError()) != hipSuccess) return fe;
+            if (side) return hipEventRecord(conc.join, conc.side);
+            return hipSuccess;
+        };
+        const bool want_fix = cr.fix && !(SKINRT_ABLATE & 32);
+        if (want_fix && !conc.skin2_first && (e = launch_fix()) != hipSuccess) return e;
         const dim3 grid(8u * plan.tiles_per_chunk * plan.ranges_per_chunk2), block(kSkin2Threads);
 #define SKINRT_LAUNCH2(EX, KK, LL) hipLaunchKernelGGL((k_skin2<EX, KK, LL>), grid, block, plan.lds_bytes2, s, rig, cr, plan)
         if (plan.look2 == 1) {
@@ -1263,19 +1385,10 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         }
 #undef SKINRT_LAUNCH2
         e = hipGetLastError();
-        if (e == hipSuccess && cr.fix && !(SKINRT_ABLATE & 32)) {  // what k_skin2 handed over (the count is on the device: fixed grid)
-            // one block per (tile, chunk lane).  Lists are uneven (tiles with many pairs hand over most), so there are
-            // enough lanes that the longest list is a few chunks per block; blocks past a list's end leave at once
-            const uint32_t lanes = std::min((cr.I + kFixChunk - 1) / kFixChunk, std::max(1u, 32768u / rig.T));
-            const dim3 fgrid(8u * ((rig.T + 7) / 8) * lanes), fblock(256);
-            if (rig.K == 1) {
-                if (plan.exact) hipLaunchKernelGGL((k_skin_fix<true, 1>), fgrid, fblock, 0, s, rig, cr, plan);
-                else hipLaunchKernelGGL((k_skin_fix<false, 1>), fgrid, fblock, 0, s, rig, cr, plan);
-            } else {
-                if (plan.exact) hipLaunchKernelGGL((k_skin_fix<true, 2>), fgrid, fblock, 0, s, rig, cr, plan);
-                else hipLaunchKernelGGL((k_skin_fix<false, 2>), fgrid, fblock, 0, s, rig, cr, plan);
-            }
-            e = hipGetLastError();
+        if (e == hipSuccess && want_fix && conc.skin2_first) e = launch_fix();
+        if (side && want_fix) {  // join even after a failed launch: the side stream's work may already be enqueued
+            const hipError_t je = hipStreamWaitEvent(s, conc.join, 0);
+            if (e == hipSuccess) e = je;
         }
     }
     // the loader-wave kernel's LDS need is checked only when it is launched at all (skinrt_create_crowd refuses such rigs)

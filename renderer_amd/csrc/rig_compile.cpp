@@ -147,6 +147,7 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
     REQUIRE(r.clips == 0 || d->clips, SKINRT_E_INVALID, "clips is NULL");
     r.node_chan.assign((size_t)r.clips * N * 3, -1);
     r.clip_chan_count.resize(r.clips);
+    r.clip_weights_chan.assign(r.clips, -1);
     r.Cmax = 0;
     for (uint32_t c = 0; c < r.clips; ++c) {
         const skinrt_clip_desc& cl = d->clips[c];
@@ -157,17 +158,26 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
         for (uint32_t k = 0; k < cl.channel_count; ++k) {
             const skinrt_channel_desc& ch = cl.channels[k];
             REQUIRE(ch.target_node < N, SKINRT_E_RANGE, "channel target_node out of range");
-            REQUIRE(ch.path <= SKINRT_PATH_SCALE, SKINRT_E_INVALID, "channel path invalid (MorphTargetWeights is todo!() in the reference, loader/gltf/mod.rs:1312)");
+            REQUIRE(ch.path <= SKINRT_PATH_WEIGHTS, SKINRT_E_INVALID, "channel path invalid");
+            const bool wchan = ch.path == SKINRT_PATH_WEIGHTS;
+            REQUIRE(!wchan || M > 0, SKINRT_E_INVALID, "weights channel on a rig without morph targets");
             REQUIRE(ch.interpolation <= SKINRT_INTERP_CUBICSPLINE, SKINRT_E_INVALID, "channel interpolation invalid");
             REQUIRE(ch.key_count >= 1 && ch.times && ch.values, SKINRT_E_INVALID, "channel without keyframes");
-            const uint32_t w = ch.path == SKINRT_PATH_ROTATION ? 4 : 3;
+            const uint32_t w = wchan ? M : (ch.path == SKINRT_PATH_ROTATION ? 4 : 3);
             const uint32_t per_key = (ch.interpolation == SKINRT_INTERP_CUBICSPLINE ? 3 : 1) * w;
             REQUIRE(finite_all(ch.times, ch.key_count), SKINRT_E_INVALID, "non-finite key time");
             for (uint32_t i = 1; i < ch.key_count; ++i)
                 REQUIRE(ch.times[i] >= ch.times[i - 1], SKINRT_E_INVALID, "key times are not sorted");
-            int32_t& slot = r.node_chan[((size_t)c * N + ch.target_node) * 3 + ch.path];
-            REQUIRE(slot < 0, SKINRT_E_INVALID, "two channels of one clip target the same node property");
-            slot = (int32_t)r.chans.size();
+            if (wchan) {
+                REQUIRE(r.clip_weights_chan[c] < 0, SKINRT_E_INVALID, "two weights channels in one clip");
+                REQUIRE(finite_all(ch.values, (size_t)ch.key_count * per_key), SKINRT_E_INVALID, "non-finite morph weight key");
+                r.clip_weights_chan[c] = (int32_t)r.chans.size();
+                ++r.weight_channel_clips;
+            } else {
+                int32_t& slot = r.node_chan[((size_t)c * N + ch.target_node) * 3 + ch.path];
+                REQUIRE(slot < 0, SKINRT_E_INVALID, "two channels of one clip target the same node property");
+                slot = (int32_t)r.chans.size();
+            }
             ChanRec rec;
             rec.key_count = ch.key_count;
             rec.time_off = (uint32_t)r.times.size();
@@ -391,6 +401,7 @@ void fill_rig_info(const CompiledRig& r, uint64_t device_bytes, skinrt_rig_info*
     info->device_bytes = device_bytes;
     info->exact_arithmetic = r.exact;
     info->bind_extent = r.bind_extent;
+    info->weight_channel_clips = r.weight_channel_clips;
 }
 
 }  // namespace skinrt

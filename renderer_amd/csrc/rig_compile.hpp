@@ -68,6 +68,8 @@ struct CompiledRig {
     std::vector<int32_t> node_chan;     // [clips][N][3] global channel index or -1
     std::vector<ChanRec> chans;
     std::vector<uint32_t> clip_chan_count;  // [clips]
+    std::vector<int32_t> clip_weights_chan; // [clips] global index of the clip's SKINRT_PATH_WEIGHTS channel, or -1
+    uint32_t weight_channel_clips = 0;      // clips that have one
     std::vector<float> times, values;
     // skin
     std::vector<uint32_t> joint_node;   // [J]

@@ -41,6 +41,36 @@ def all_gather_rows(local, instances: int, world: int, group=None):
     return out[:instances]
 
 
+def all_gather_rows_chunked(tensors, instances: int, world: int, budget_bytes: int = 8 << 30, consume=None, group=None):
+    """All-gather several per-instance row arrays (`tensors`: [n_local, W] each, e.g. position / normal /
+    tangent) one after the other through ONE bounded buffer: row chunks sized so that the gathered chunk
+    stays under `budget_bytes`.  After each collective `consume(k, r0, r1, view)` (if given) sees the chunk:
+    view[g, j] = row r0 + j of rank g's shard of tensors[k] (the last rank's missing rows are zero).
+    Returns the bytes every rank received."""
+    import torch
+    import torch.distributed as dist
+
+    per = padded_count(instances, world)
+    width = int(tensors[0].shape[1])
+    row_bytes = width * tensors[0].element_size()
+    rows = max(1, min(max(per, 1), budget_bytes // max(1, world * row_bytes)))
+    buf = torch.empty((world * rows, width), dtype=tensors[0].dtype, device=tensors[0].device)
+    moved = 0
+    for k, t in enumerate(tensors):
+        for r0 in range(0, per, rows):
+            r1 = min(per, r0 + rows)
+            part = t[min(r0, t.shape[0]):min(r1, t.shape[0])]
+            if part.shape[0] != r1 - r0:  # a short (last) shard: pad
+                pad = torch.zeros((r1 - r0 - part.shape[0], width), dtype=t.dtype, device=t.device)
+                part = torch.cat([part, pad], dim=0)
+            out = buf[: world * (r1 - r0)]
+            dist.all_gather_into_tensor(out, part.contiguous(), group=group)
+            moved += world * (r1 - r0) * row_bytes
+            if consume is not None:
+                consume(k, r0, r1, out.view(world, r1 - r0, width))
+    return moved
+
+
 class DeviceArray:
     """Zero-copy view of a libskinrt device buffer for torch (`torch.as_tensor(DeviceArray(...),
     device='cuda')`), via __cuda_array_interface__."""

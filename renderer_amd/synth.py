@@ -16,7 +16,7 @@ from typing import Dict, Optional
 import numpy as np
 
 from .abi import (INTERP_CUBICSPLINE, INTERP_LINEAR, INTERP_STEP, PATH_ROTATION, PATH_SCALE,
-                  PATH_TRANSLATION, Channel, MorphTarget, RigData)
+                  PATH_TRANSLATION, PATH_WEIGHTS, Channel, MorphTarget, RigData)
 
 
 def _rng(seed: int, stream: int = 0) -> np.random.Generator:
@@ -87,6 +87,7 @@ class SynthSpec:
     scatter_joints: bool = False   # True: influences uniform over all joints (worst-case locality)
     instances: int = 1
     morph_zero_frac: float = 0.75
+    weight_channels: int = 0       # clips 0 .. weight_channels-1 carry a glTF "weights" channel (interpolation cycles LINEAR, CUBICSPLINE, STEP)
 
 
 CONFIGS: Dict[str, SynthSpec] = {
@@ -226,6 +227,37 @@ def make_rig(spec: SynthSpec) -> RigData:
         # file order of channels is arbitrary in glTF: shuffle
         order = ra.permutation(len(chans))
         clips.append([chans[i] for i in order])
+    # glTF "weights" channels (animated expressions): own stream, so rigs without them are unchanged.  Keys are
+    # exactly zero for most targets most of the time, as expressions are.
+    if spec.weight_channels and spec.targets:
+        rw = _rng(spec.seed, 4)
+        M = spec.targets
+        for c in range(min(spec.weight_channels, len(clips))):
+            length = spec.clip_len * (1.0 + 0.25 * c)
+            interp = (INTERP_LINEAR, INTERP_CUBICSPLINE, INTERP_STEP)[c % 3]
+            kf = max(2, spec.keys // 2)
+            times = np.sort(rw.uniform(0, length, size=kf)).astype(np.float32)
+            times[0] = np.float32(0.1 * length)   # late first key, early last key: both clamps are exercised
+            times[-1] = np.float32(0.9 * length)
+            times = np.sort(times)
+            for k in range(1, kf):
+                if times[k] <= times[k - 1]:
+                    times[k] = np.nextafter(times[k - 1], np.float32(np.inf))
+            base = rw.uniform(0, 1, size=(kf, M)).astype(np.float32)
+            on = rw.random((kf, M)) < 0.5
+            on[:, rw.random(M) < 0.6] = False      # most targets stay off for the whole clip
+            base[~on] = 0.0
+            if interp == INTERP_CUBICSPLINE:
+                vals = np.zeros((kf, 3, M), dtype=np.float32)
+                vals[:, 1] = base
+                tang = rw.normal(scale=0.05, size=(2, kf, M)).astype(np.float32)
+                tang[:, ~(on | np.roll(on, 1, axis=0) | np.roll(on, -1, axis=0))] = 0.0  # off segments stay exactly zero
+                vals[:, 0] = tang[0]
+                vals[:, 2] = tang[1]
+            else:
+                vals = base
+            node = int(joint_node[0])
+            clips[c].insert(int(rw.integers(0, len(clips[c]) + 1)), Channel(node, PATH_WEIGHTS, interp, times, vals))
 
     # morph targets
     rm = _rng(spec.seed, 3)

@@ -62,3 +62,42 @@ def assert_equal(got, ref, what):
     if neq.any():
         idx = np.unravel_index(np.argmax(neq), neq.shape)
         raise AssertionError(f"{what}: {int(neq.sum())}/{neq.size} differ; first at {idx}: got {got[idx]!r} ref {ref[idx]!r}")
+
+
+import ctypes as C
+
+
+class DeviceBuffers:
+    """Caller-owned device memory (plain HIP through ctypes: the caller's business, not the library's)."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.ptrs = []
+
+    def _ok(self, rc):
+        assert rc == 0, f"HIP error {rc}"
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        p = C.c_void_p()
+        self._ok(self.hip.hipMalloc(C.byref(p), C.c_size_t(max(a.nbytes, 4))))
+        self._ok(self.hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), C.c_int(1)))
+        self.ptrs.append(p)
+        return p.value
+
+    def empty(self, nbytes, fill=0xAB):
+        p = C.c_void_p()
+        self._ok(self.hip.hipMalloc(C.byref(p), C.c_size_t(max(nbytes, 4))))
+        self._ok(self.hip.hipMemset(p, C.c_int(fill), C.c_size_t(max(nbytes, 4))))
+        self.ptrs.append(p)
+        return p.value
+
+    def download(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype)
+        self._ok(self.hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(out.nbytes), C.c_int(2)))
+        return out
+
+    def close(self):
+        for p in self.ptrs:
+            self.hip.hipFree(p)
+        self.ptrs = []

@@ -155,10 +155,33 @@ def test_duplicate_channel_target():
     expect(rig, abi.E_INVALID, "same node property")
 
 
-def test_morph_weight_channel_path_rejected():
+def test_channel_path_out_of_range_rejected():
     _, rig = tiny()
-    rig.clips[0][0].path = 3   # MorphTargetWeights: todo!() in the reference loader
+    rig.clips[0][0].path = 4
     expect(rig, abi.E_INVALID, "channel path invalid")
+
+
+def test_weights_channel_validation():
+    """SKINRT_PATH_WEIGHTS (the reference: todo!(), loader/gltf/mod.rs:1312): width = target_count, one per clip,
+    only on rigs with morph targets, finite keys."""
+    spec = synth.tiny_spec(seed=5, weight_channels=1)
+    rig = synth.make_rig(spec)
+    info = api.validate_rig(rig)
+    assert info.weight_channel_clips == 1
+    wch = [ch for ch in rig.clips[0] if ch.path == abi.PATH_WEIGHTS]
+    assert len(wch) == 1 and wch[0].values.shape[-1] == rig.target_count
+    # a second one in the same clip
+    rig.clips[0].append(abi.Channel(0, abi.PATH_WEIGHTS, abi.INTERP_STEP, wch[0].times.copy(), wch[0].values.reshape(len(wch[0].times), -1)[:, :rig.target_count].copy()))
+    expect(rig, abi.E_INVALID, "two weights channels")
+    # non-finite key
+    rig = synth.make_rig(spec)
+    w = [ch for ch in rig.clips[0] if ch.path == abi.PATH_WEIGHTS][0]
+    w.values = w.values.copy(); w.values.reshape(-1)[0] = np.inf
+    expect(rig, abi.E_INVALID, "non-finite morph weight key")
+    # no morph targets at all
+    rig = synth.make_rig(synth.tiny_spec(seed=5, targets=0))
+    rig.clips[0].append(abi.Channel(0, abi.PATH_WEIGHTS, abi.INTERP_STEP, np.zeros(1, np.float32), np.zeros((1, 1), np.float32)))
+    expect(rig, abi.E_INVALID, "without morph targets")
 
 
 def test_channel_target_out_of_range():

@@ -72,6 +72,19 @@ if rank == 0:
     assert np.array_equal(all_aabb.numpy().view(np.uint32), ref.aabb.reshape(I, 6).view(np.uint32))
     assert np.array_equal(all_pos.numpy().view(np.uint32), ref.position.view(np.uint32))
     print("GATHER_OK", I, world)
+# the chunked gather of several attributes through one bounded buffer (bench.py's vertex all-gather)
+per = shard.padded_count(I, world)
+flat = pos.reshape(hi - lo, V * 3)
+got = [np.zeros((world * per, V * 3), np.float32) for _ in range(2)]
+def consume(k, r0, r1, view):
+    for g in range(world):
+        got[k][g * per + r0: g * per + r1] = view[g].numpy()
+moved = shard.all_gather_rows_chunked([flat, flat * 2.0], I, world, budget_bytes=world * V * 12 * 2, consume=consume)
+assert moved == 2 * world * per * V * 12
+if rank == 0:
+    assert np.array_equal(got[0][:I].view(np.uint32), ref.position.reshape(I, V * 3).view(np.uint32))
+    assert np.array_equal(got[1][:I], ref.position.reshape(I, V * 3) * 2.0)
+    print("CHUNKED_OK", I, world)
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -93,3 +106,4 @@ def test_world_size_2_gather_is_byte_identical(instances, tmp_path):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert f"GATHER_OK {instances} 2" in p.stdout
+    assert f"CHUNKED_OK {instances} 2" in p.stdout

@@ -6,7 +6,7 @@ they are not frames and are left out.  `--csv` prints the per-kernel table as CS
 import csv, glob, os, sys, collections
 d = sys.argv[1]
 as_csv = "--csv" in sys.argv
-KERNELS = ("k_skin_fix", "k_skin2", "k_skin", "k_pose_wave", "k_propagate_quad", "k_aabb_reduce", "k_sample_local",
+KERNELS = ("k_classify", "k_export_interleaved", "k_export_skin_uniform", "k_sample_weights", "k_skin_fix", "k_skin2", "k_skin", "k_pose_wave", "k_propagate_quad", "k_aabb_reduce", "k_sample_local",
            "k_palette", "k_fill_mw")
 def short(n):
     for k in KERNELS:
@@ -33,7 +33,22 @@ for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursiv
         print(f"  {k:18s} calls={len(v):5d} avg_ns={sum(v)/len(v):12.0f} min_ns={min(v):10d} max_ns={max(v):10d} total%={100.0*sum(v)/tot:.2f}")
     skin = [acc.get("k_skin2", []), acc.get("k_skin_fix", []), acc.get("k_skin", [])]
     per_frame = sum(sum(v) / len(v) for v in skin if v)
-    print(f"  skin stage per frame (k_skin2 + k_skin_fix + k_skin averages): {per_frame / 1e6:.3f} ms")
+    print(f"  sum of the skin kernels' average durations (k_skin2 + k_skin_fix + k_skin): {per_frame / 1e6:.3f} ms")
+    # k_skin_fix runs NEXT TO k_skin2 (side stream): the stage is the span from its first kernel's start
+    # (k_classify, or k_skin2 for rigs without morph targets) to the last end of its kernels, per frame
+    stage = ("k_classify", "k_skin2", "k_skin_fix", "k_skin")
+    evs = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows if short(r["Kernel_Name"]) in stage))
+    has_classify = any(e[2] == "k_classify" for e in evs)
+    spans, cur = [], None
+    for st, en, name in evs:
+        if name == ("k_classify" if has_classify else "k_skin2"):
+            if cur: spans.append(cur[1] - cur[0])
+            cur = [st, en]
+        elif cur:
+            cur[1] = max(cur[1], en)
+    if cur: spans.append(cur[1] - cur[0])
+    if spans:
+        print(f"  skin stage span per frame (first start -> last end of k_classify / k_skin2 / k_skin_fix): avg {sum(spans)/len(spans)/1e6:.3f} ms, min {min(spans)/1e6:.3f}, max {max(spans)/1e6:.3f} over {len(spans)} frames")
 for p in sorted(glob.glob(os.path.join(d, "pmc*"))):
     if not os.path.isdir(p): continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
