@@ -134,9 +134,12 @@ struct AnimationKeyFrames {
 };
 
 struct AnimationSampler {
-    enum class Kind { Rotation, Translation, Scale } kind = Kind::Translation;
+    // MorphTargetWeights: the variant the reference's loader has not written yet (Property::MorphTargetWeights =>
+    // todo!(), loader/gltf/mod.rs:1312); here: M floats per key, M = the morphed mesh's target count
+    enum class Kind { Rotation, Translation, Scale, MorphTargetWeights } kind = Kind::Translation;
     AnimationKeyFrames<std::array<float, 4>> rotation;
     AnimationKeyFrames<std::array<float, 3>> vec3;  // Translation / Scale
+    AnimationKeyFrames<std::vector<float>> weights; // MorphTargetWeights
 };
 
 struct AnimationChannelAsset {

@@ -2,6 +2,7 @@
 #include "flatten.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 namespace skinrt_host {
@@ -40,9 +41,9 @@ struct Walk {
     }
 };
 
-template <class T, size_t W>
-void push_keys(const AnimationKeyFrames<std::array<T, W>>& k, FlatChannel& ch) {
-    using Kind = typename AnimationKeyFrames<std::array<T, W>>::Kind;
+template <class V>
+void push_keys(const AnimationKeyFrames<V>& k, FlatChannel& ch) {
+    using Kind = typename AnimationKeyFrames<V>::Kind;
     if (k.kind == Kind::CubicSpline) {
         ch.interpolation = SKINRT_INTERP_CUBICSPLINE;
         for (const auto& f : k.cubic_frames) {
@@ -109,6 +110,7 @@ int flatten(const std::vector<SceneAsset>& scenes, const std::vector<AnimationAs
                 case AnimationSampler::Kind::Rotation: ch.path = SKINRT_PATH_ROTATION; push_keys(c.sampler.rotation, ch); break;
                 case AnimationSampler::Kind::Translation: ch.path = SKINRT_PATH_TRANSLATION; push_keys(c.sampler.vec3, ch); break;
                 case AnimationSampler::Kind::Scale: ch.path = SKINRT_PATH_SCALE; push_keys(c.sampler.vec3, ch); break;
+                case AnimationSampler::Kind::MorphTargetWeights: ch.path = SKINRT_PATH_WEIGHTS; push_keys(c.sampler.weights, ch); break;
             }
             length = std::max(length, c.length);
             clip.push_back(std::move(ch));
@@ -183,8 +185,14 @@ int flatten(const std::vector<SceneAsset>& scenes, const std::vector<AnimationAs
                         dst.normal.insert(dst.normal.end(), x.begin(), x.end());
                     }
                     if (any_tangent[m]) {
+                        // Deviation from the loader's data, on purpose: a target without a TANGENT accessor gets
+                        // calculate_tangent(delta positions) from the loader (as the reference, loader/gltf/mod.rs:911-916),
+                        // which is 0 * inf = NaN for every vertex whose triangles do not move.  A NaN delta would turn the
+                        // vertex's tangent into NaN at ANY weight (0 * NaN), so non-finite tangent deltas become zero here.
                         const std::array<float, 4> z{0, 0, 0, 0};
-                        const auto& x = src.tangent.empty() ? z : src.tangent[v];
+                        std::array<float, 4> x = src.tangent.empty() ? z : src.tangent[v];
+                        for (float& e : x)
+                            if (!std::isfinite(e)) { e = 0.0f; ++rig.sanitized_tangent_deltas; }
                         dst.tangent.insert(dst.tangent.end(), x.begin(), x.end());
                     }
                 }
@@ -198,6 +206,20 @@ int flatten(const std::vector<SceneAsset>& scenes, const std::vector<AnimationAs
         const std::vector<float>& src = !n0.weights.empty() ? n0.weights : n0.mesh->weights;
         rig.default_weights.assign(M, 0.0f);
         std::copy_n(src.begin(), std::min(src.size(), M), rig.default_weights.begin());
+    }
+    // weights channels: the C ABI reads key_count x M (x 3) floats — check the width here, where the lengths are known.
+    // A channel aimed at a mesh node that is not part of the flattened skin is dropped (its mesh is not in the rig).
+    for (auto& clip : rig.clips) {
+        for (size_t k = 0; k < clip.size();) {
+            FlatChannel& ch = clip[k];
+            if (ch.path != SKINRT_PATH_WEIGHTS) { ++k; continue; }
+            const bool ours = std::any_of(w.skinned.begin(), w.skinned.end(), [&](const auto& sk) { return sk.node == ch.node; });
+            if (!ours || M == 0) { clip.erase(clip.begin() + (long)k); continue; }
+            const size_t per_key = (ch.interpolation == SKINRT_INTERP_CUBICSPLINE ? 3 : 1) * M;
+            if (ch.values.size() != ch.times.size() * per_key)
+                return fail(err, SKINRT_E_INVALID, "weights channel: values per key != morph target count of the mesh");
+            ++k;
+        }
     }
     return SKINRT_OK;
 }

@@ -56,6 +56,7 @@ struct FlatRig {
     std::vector<std::vector<float>> weights;       // K x [V][4]
     std::vector<FlatTarget> targets;
     std::vector<float> default_weights;
+    uint64_t sanitized_tangent_deltas = 0;         // non-finite morph tangent deltas replaced by zero (flatten.cpp)
     std::vector<PrimitiveRange> ranges;
 
     uint32_t node_count() const { return (uint32_t)parent.size(); }

@@ -347,11 +347,11 @@ struct Loader {
     }
 
     // load_animation_sampler (:1219-1300)
-    template <class T, size_t W>
-    static float read_keyframes(const std::vector<float>& time, const std::vector<std::array<T, W>>& data, bool cubic,
-                                AnimationKeyFrames<std::array<T, W>>& out, const std::string& interpolation) {
-        using KF = AnimationKeyFrames<std::array<T, W>>;
-        std::vector<AnimationKeyFrame<std::array<T, W>>> frames;
+    template <class V>
+    static float read_keyframes(const std::vector<float>& time, const std::vector<V>& data, bool cubic,
+                                AnimationKeyFrames<V>& out, const std::string& interpolation) {
+        using KF = AnimationKeyFrames<V>;
+        std::vector<AnimationKeyFrame<V>> frames;
         const size_t repeat = cubic ? 3 : 1;
         const size_t n = std::min(time.size() * repeat, data.size());  // zip stops at the shorter side
         for (size_t k = 0; k < n; ++k) frames.push_back({time[k / repeat], data[k]});
@@ -394,7 +394,18 @@ struct Loader {
                 c.sampler.kind = path == "scale" ? AnimationSampler::Kind::Scale : AnimationSampler::Kind::Translation;
                 c.length = read_keyframes(time, chunk<float, 3>(load_accessor_f32(d, outa)), cubic, c.sampler.vec3, interpolation);
             } else if (path == "weights") {
-                fail(SKINRT_E_INVALID, "MorphTargetWeights channel (reference: todo!(), loader/gltf/mod.rs:1312)");
+                // Property::MorphTargetWeights => todo!() in the reference (loader/gltf/mod.rs:1312).  glTF: the output
+                // accessor holds M scalars per key (3 M for CUBICSPLINE), float or normalised integer, M = the number of
+                // morph targets of the node's mesh; read like the other samplers (times repeated for the spline triple).
+                if (outa.dims != "SCALAR") fail(SKINRT_E_INVALID, "BadAccessorDimensions (animation weights)");
+                const std::vector<float> flat = load_accessor_normalized(d, outa);
+                const size_t rows = time.size() * (cubic ? 3 : 1);
+                if (rows == 0 || flat.size() % rows != 0 || flat.empty()) fail(SKINRT_E_INVALID, "animation weights: output count is not keys x targets");
+                const size_t M = flat.size() / rows;
+                std::vector<std::vector<float>> data(rows);
+                for (size_t k = 0; k < rows; ++k) data[k].assign(flat.begin() + k * M, flat.begin() + (k + 1) * M);
+                c.sampler.kind = AnimationSampler::Kind::MorphTargetWeights;
+                c.length = read_keyframes(time, data, cubic, c.sampler.weights, interpolation);
             } else {
                 fail(SKINRT_E_INVALID, "animation target path invalid");
             }

@@ -95,6 +95,8 @@ float skinrt_host_rig_clip_length(const skinrt_host_rig* rig, uint32_t clip) {
     return (rig && clip < rig->flat.clip_length.size()) ? rig->flat.clip_length[clip] : 0.0f;
 }
 
+uint64_t skinrt_host_rig_sanitized_tangent_deltas(const skinrt_host_rig* rig) { return rig ? rig->flat.sanitized_tangent_deltas : 0; }
+
 void skinrt_host_free_rig(skinrt_host_rig* rig) { delete rig; }
 
 const char* skinrt_host_last_error(void) { return g_error.c_str(); }

@@ -32,6 +32,9 @@ SKINRT_API const skinrt_rig_desc* skinrt_host_rig_desc(skinrt_host_rig* rig);
 SKINRT_API uint32_t skinrt_host_rig_node_gltf_index(const skinrt_host_rig* rig, uint32_t n);
 /* max over channels of AnimationChannelAsset.length */
 SKINRT_API float skinrt_host_rig_clip_length(const skinrt_host_rig* rig, uint32_t clip);
+/* non-finite morph-target tangent deltas the flattener replaced by zero (flatten.cpp: targets without a TANGENT
+ * accessor get generated tangents, NaN wherever the delta mesh does not move) */
+SKINRT_API uint64_t skinrt_host_rig_sanitized_tangent_deltas(const skinrt_host_rig* rig);
 SKINRT_API void skinrt_host_free_rig(skinrt_host_rig* rig);
 SKINRT_API const char* skinrt_host_last_error(void);
 /* calculate_tangent (renderer-asset/src/tangent.rs:15-58); mode: 0 Points, 1 LineStrip,

@@ -44,6 +44,8 @@ def load_library() -> C.CDLL:
         lib.skinrt_host_rig_node_gltf_index.restype = C.c_uint32
         lib.skinrt_host_rig_clip_length.argtypes = [C.c_void_p, C.c_uint32]
         lib.skinrt_host_rig_clip_length.restype = C.c_float
+        lib.skinrt_host_rig_sanitized_tangent_deltas.argtypes = [C.c_void_p]
+        lib.skinrt_host_rig_sanitized_tangent_deltas.restype = C.c_uint64
         lib.skinrt_host_free_rig.argtypes = [C.c_void_p]
         lib.skinrt_host_free_rig.restype = None
         lib.skinrt_host_last_error.restype = C.c_char_p
@@ -69,7 +71,8 @@ def _rig_from_desc(d: RigDesc) -> RigData:
         chans = []
         for k in range(cl.channel_count):
             ch = cl.channels[k]
-            w = (4 if ch.path == abi.PATH_ROTATION else 3) * (3 if ch.interpolation == abi.INTERP_CUBICSPLINE else 1)
+            w = d.target_count if ch.path == abi.PATH_WEIGHTS else (4 if ch.path == abi.PATH_ROTATION else 3)
+            w *= 3 if ch.interpolation == abi.INTERP_CUBICSPLINE else 1
             chans.append(Channel(ch.target_node, ch.path, ch.interpolation, _np(ch.times, (ch.key_count,), np.float32),
                                  _np(ch.values, (ch.key_count, w), np.float32)))
         clips.append(chans)
@@ -107,6 +110,7 @@ def load_glb(data: bytes, scene: int = -1) -> Tuple[RigData, np.ndarray, np.ndar
         rig = _rig_from_desc(d)
         order = np.array([lib.skinrt_host_rig_node_gltf_index(h, k) for k in range(d.node_count)], np.uint32)
         lengths = np.array([lib.skinrt_host_rig_clip_length(h, c) for c in range(d.clip_count)], np.float32)
+        rig.sanitized_tangent_deltas = int(lib.skinrt_host_rig_sanitized_tangent_deltas(h))
         return rig, order, lengths
     finally:
         lib.skinrt_host_free_rig(h)

@@ -10,7 +10,7 @@ import numpy as np
 
 from .abi import Channel, MorphTarget, RigData
 
-_VALUE_WIDTH = {0: 3, 1: 4, 2: 3}  # translation, rotation, scale
+_VALUE_WIDTH = {0: 3, 1: 4, 2: 3}  # translation, rotation, scale; weights (path 3): the rig's target count
 
 
 def rig_to_arrays(rig: RigData, prefix: str = "rig_") -> Dict[str, np.ndarray]:
@@ -60,8 +60,9 @@ def rig_from_arrays(z, prefix: str = "rig_") -> RigData:
     clips = [[] for _ in range(int(g("clip_count")[0]))]
     to = vo = 0
     times, values = g("channel_times"), g("channel_values")
+    n_targets = int(g("targets").shape[0])
     for ci, node, path, interp, kc in g("channels").tolist():
-        w = _VALUE_WIDTH[path] * (3 if interp == 2 else 1)
+        w = (n_targets if path == 3 else _VALUE_WIDTH[path]) * (3 if interp == 2 else 1)
         clips[ci].append(Channel(node, path, interp, times[to:to + kc].copy(), values[vo:vo + kc * w].reshape(kc, -1).copy()))
         to += kc; vo += kc * w
     targets = []

@@ -45,7 +45,7 @@ def _f(x):
     return [float(v) for v in np.asarray(x, np.float32).reshape(-1)]
 
 
-def write_glb(rig, seed=0, joints_u8=False, weights_u16=False, interleave=True, omit_ibm=False, mesh_node=0):
+def write_glb(rig, seed=0, joints_u8=False, weights_u16=False, interleave=True, omit_ibm=False, mesh_node=0, omit_target_tangent=False):
     """Returns (glb bytes, perm) where perm[flat node] = glTF node index."""
     rng = np.random.default_rng(seed)
     n = rig.node_count
@@ -105,7 +105,7 @@ def write_glb(rig, seed=0, joints_u8=False, weights_u16=False, interleave=True, 
         # the reference wants VEC4 here and GENERATES tangents when the accessor is absent: always write one
         dt4 = np.zeros((v, 4), np.float32)
         if dt is not None: dt4[:, :3] = dt
-        tj["TANGENT"] = b.add(dt4, F32, "VEC4")
+        if not omit_target_tangent: tj["TANGENT"] = b.add(dt4, F32, "VEC4")
         targets.append(tj)
     if targets: prim["targets"] = targets
     mesh = {"primitives": [prim]}
@@ -118,8 +118,14 @@ def write_glb(rig, seed=0, joints_u8=False, weights_u16=False, interleave=True, 
     for clip in rig.clips:
         samplers, channels = [], []
         for ch in clip:
-            w = 4 if ch.path == 1 else 3
             interp = ["LINEAR", "STEP", "CUBICSPLINE"][ch.interpolation]
+            if ch.path == 3:  # "weights": M scalars per key (3 M for the spline triple), aimed at the node that carries the mesh
+                out = np.asarray(ch.values, np.float32).reshape(-1)
+                samplers.append({"input": b.add(np.asarray(ch.times, np.float32), F32, "SCALAR"),
+                                 "output": b.add(out, F32, "SCALAR"), "interpolation": interp})
+                channels.append({"sampler": len(samplers) - 1, "target": {"node": int(perm[mesh_node]), "path": "weights"}})
+                continue
+            w = 4 if ch.path == 1 else 3
             out = np.asarray(ch.values, np.float32).reshape(-1, w)  # cubic: (in, value, out) per key = 3 rows per key
             samplers.append({"input": b.add(np.asarray(ch.times, np.float32), F32, "SCALAR"),
                              "output": b.add(out, F32, "VEC4" if w == 4 else "VEC3"), "interpolation": interp})

@@ -39,6 +39,8 @@ FIXTURES = {
     "tiny_normalized": (synth.tiny_spec(seed=103), 3, 1, 1, False),
     "tiny_two_sets_sparse": (synth.tiny_spec(seed=104, sets=2, target_mode="sparse", target_frac=0.3, targets=4), 4, 1, 0, True),
     "tiny_no_clips_no_targets": (synth.tiny_spec(seed=105, clips=0, targets=0), 2, 1, 0, False),
+    # glTF "weights" channels on clips 0 (LINEAR) and 1 (CUBICSPLINE); clip 2 has none
+    "tiny_weight_channels": (synth.tiny_spec(seed=106, clips=3, keys=5, weight_channels=2, targets=5), 9, 1, 0, False),
     # one mid-size per config shape, scaled down
     "c1_shape": (synth.CONFIGS["c1"], 1, 1, 0, False),
     "c2_shape": (synth.CONFIGS["c2"], 6, 1, 0, True),
@@ -62,7 +64,10 @@ def make(name):
 
 
 def main():
+    only = sys.argv[1:]
     for name in FIXTURES:
+        if only and name not in only:
+            continue
         rig, extra = make(name)
         path = os.path.join(HERE, name + ".npz")
         rigfile.save_rig(path, rig, **extra)

@@ -132,7 +132,8 @@ def test_errors_where_the_reference_panics():
     glb, _ = write_glb(rig, seed=3)
     _expect(b"nope" + glb[4:], abi.E_INVALID, "magic")
     _expect(_edit(glb, lambda d: d["meshes"][0]["primitives"][0]["attributes"].pop("POSITION")), abi.E_INVALID, "No positions")
-    _expect(_edit(glb, lambda d: d["animations"][0]["channels"][0]["target"].update(path="weights")), abi.E_INVALID, "todo!()")
+    # a "weights" channel whose output is not SCALAR, or not keys x targets long
+    _expect(_edit(glb, lambda d: d["animations"][0]["channels"][0]["target"].update(path="weights")), abi.E_INVALID, "BadAccessorDimensions (animation weights)")
     _expect(_edit(glb, lambda d: d["accessors"][d["meshes"][0]["primitives"][0]["attributes"]["WEIGHTS_0"]].update(componentType=5122)),
             abi.E_INVALID, "signed normalised")
     _expect(_edit(glb, lambda d: d["bufferViews"][0].update(byteOffset=10 ** 9)), abi.E_RANGE, "past its buffer")
@@ -256,6 +257,66 @@ def test_host_calculate_tangent_equals_the_oracle_restatement(oracle32):
     for args in ((4, pos, idx), (4, pos[:300]), (0, pos[:10]), (2, pos[:10])):
         got, want = hostlib.calculate_tangent(*args), oracle32.calculate_tangent(*args)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_weights_channels_round_trip_through_glb(oracle32):
+    """glTF "weights" animation channels (the reference: Property::MorphTargetWeights => todo!(), loader/gltf/mod.rs:1312):
+    written as SCALAR outputs aimed at the mesh node, loaded into AnimationSampler::MorphTargetWeights, flattened to
+    SKINRT_PATH_WEIGHTS with width = target count; the loaded rig evaluates like the source rig."""
+    spec = synth.tiny_spec(seed=61, clips=3, keys=5, targets=4, weight_channels=3)
+    rig = synth.make_rig(spec)
+    glb, perm = write_glb(rig, seed=4)
+    loaded, order, _ = hostlib.load_glb(glb)
+    src = [[ch for ch in clip if ch.path == abi.PATH_WEIGHTS] for clip in rig.clips]
+    got = [[ch for ch in clip if ch.path == abi.PATH_WEIGHTS] for clip in loaded.clips]
+    assert [len(c) for c in got] == [1, 1, 1]
+    for a, b in zip(src, got):
+        assert a[0].interpolation == b[0].interpolation
+        assert np.array_equal(a[0].times, b[0].times)
+        assert np.array_equal(np.asarray(a[0].values).reshape(-1), np.asarray(b[0].values).reshape(-1))
+    assert api.validate_rig(loaded).weight_channel_clips == 3
+    crowd = synth.make_crowd(spec, rig, instances=9)
+    ra = oracle32.evaluate(rig, crowd.tau, crowd.clip_id, crowd.morph_weights, want=("position", "normal", "tangent"))
+    rb = oracle32.evaluate(loaded, crowd.tau, crowd.clip_id, crowd.morph_weights, want=("position", "normal", "tangent"))
+    for k in ("position", "normal", "tangent"):
+        assert np.array_equal(getattr(ra, k).view(np.uint32), getattr(rb, k).view(np.uint32)), k
+    # wrong width: drop one target from the mesh, the channel still carries 4 weights per key
+    bad = _edit(glb, lambda d: d["meshes"][0]["primitives"][0]["targets"].pop())
+    _expect(bad, abi.E_INVALID, "values per key != morph target count")
+
+
+def test_targets_without_tangent_accessor_load_and_validate(oracle32):
+    """a morph target without a TANGENT accessor gets calculate_tangent(delta positions) from the
+    loader, as the reference does (loader/gltf/mod.rs:911-916) — NaN for every vertex whose triangles do not move.  The
+    flattener replaces those NaN deltas by zero (documented deviation), so such a file passes skinrt_validate_rig; the
+    finite generated tangents are kept as the reference computes them."""
+    spec = synth.tiny_spec(seed=62, targets=3, target_frac=0.2)   # most vertices are not moved by a target
+    rig = synth.make_rig(spec)
+    glb, _ = write_glb(rig, seed=5, omit_target_tangent=True)
+    loaded, _, _ = hostlib.load_glb(glb)
+    assert loaded.sanitized_tangent_deltas > 0
+    for t in loaded.targets:
+        assert t.tangent is not None and np.isfinite(t.tangent).all()
+    info = api.validate_rig(loaded)
+    assert info.target_count == 3
+    crowd = synth.make_crowd(spec, rig, instances=4)
+    r = oracle32.evaluate(loaded, crowd.tau, crowd.clip_id, crowd.morph_weights, want=("position", "tangent"))
+    assert np.isfinite(r.tangent).all() and np.isfinite(r.position).all()
+
+
+@pytest.mark.gpu
+def test_glb_without_target_tangents_evaluates_on_the_gpu(oracle32):
+    spec = synth.scaled(SPECS["c3_shape"], weight_channels=1)
+    rig = synth.make_rig(spec)
+    glb, _ = write_glb(rig, seed=6, omit_target_tangent=True)
+    loaded, _, _ = hostlib.load_glb(glb)
+    assert loaded.sanitized_tangent_deltas > 0
+    crowd = synth.make_crowd(spec, rig, instances=7)
+    got = helpers.run_gpu(loaded, crowd, exact_arithmetic=1)
+    ref = helpers.run_oracle(oracle32, loaded, crowd)
+    helpers.assert_equal(got["key_index"], ref["key_index"], "key_index")
+    for k in ("world", "palette", "position", "normal", "tangent", "aabb"):
+        helpers.assert_equal(got[k].view(np.uint32), np.asarray(ref[k]).view(np.uint32), k)
 
 
 @pytest.mark.gpu

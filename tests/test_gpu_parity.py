@@ -271,6 +271,59 @@ def test_default_morph_weights_and_reset(oracle32):
     c.close(); r.close(); ctx.close()
 
 
+@pytest.mark.parametrize("exact", [1, 2])
+@pytest.mark.parametrize("shape", ["tiny", "c3"])
+def test_weights_channels_on_the_device(oracle32, shape, exact):
+    """glTF "weights" animation channels (SKINRT_PATH_WEIGHTS): the pose stage samples them into
+    the morph weights of the instances that play such a clip (LINEAR on clip 0, CUBICSPLINE on 1, STEP on 2), every
+    other instance keeps the weights the host set; key_index carries the channel's key like any other channel's."""
+    if shape == "tiny":
+        spec = synth.tiny_spec(seed=41, clips=4, keys=6, targets=5, weight_channels=3)
+        inst = 40
+    else:
+        spec = synth.scaled(synth.CONFIGS["c3"], verts=6000, clips=4, keys=12, weight_channels=3)
+        inst = 120
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=inst)
+    assert set(np.unique(crowd.clip_id)) == {0, 1, 2, 3}
+    got = run_gpu(rig, crowd, exact_arithmetic=exact)
+    assert got["info"].weight_channel_clips == 3
+    ref = run_oracle(oracle32, rig, crowd)
+    _check_all(got, ref, exact_skin=exact == 1, tag=f"weights:{shape}:")
+    # the channel really drives the mesh: instances on clips 0-2 differ from an evaluation without it
+    plain = synth.make_rig(synth.scaled(spec, weight_channels=0))
+    ref_plain = run_oracle(oracle32, plain, crowd)
+    moved = np.abs(ref["position"] - ref_plain["position"]).reshape(inst, -1).max(axis=1) > 0
+    assert moved[crowd.clip_id < 3].any() and not moved[crowd.clip_id == 3].any()
+
+
+def test_weights_channels_stage_split_and_host_weights(oracle32):
+    """The sampled weights are produced by STAGE_POSE and consumed by STAGE_SKIN; new host weights reach the
+    instances without a channel at the next frame and never the instances with one."""
+    spec = synth.tiny_spec(seed=42, clips=2, keys=4, targets=4, weight_channels=1)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=16)
+    ctx = api.Context(exact_arithmetic=1)
+    r = api.Rig(ctx, rig)
+    c = api.Crowd(ctx, r, 16)
+    c.set_clocks(crowd.tau, crowd.clip_id)
+    c.set_morph_weights(crowd.morph_weights)
+    c.evaluate(abi.STAGE_POSE, sync=True)
+    c.evaluate(abi.STAGE_SKIN | abi.STAGE_AABB, sync=True)
+    ref = oracle32.evaluate(rig, crowd.tau, crowd.clip_id, crowd.morph_weights, want=("position",))
+    assert_equal(c.positions(), ref.position, "pose then skin")
+    mw2 = (crowd.morph_weights * 0.5 + 0.125).astype(np.float32)
+    c.set_morph_weights(mw2)
+    c.evaluate(sync=True)
+    ref2 = oracle32.evaluate(rig, crowd.tau, crowd.clip_id, mw2, want=("position",))
+    got2 = c.positions()
+    assert_equal(got2, ref2.position, "new host weights")
+    with_channel = crowd.clip_id == 0
+    assert with_channel.any() and (~with_channel).any()
+    assert_equal(got2[with_channel], ref.position[with_channel], "instances with a weights channel ignore host weights")
+    c.close(); r.close(); ctx.close()
+
+
 def test_reference_layout_exports(oracle32):
     spec = synth.tiny_spec(seed=2)
     rig = synth.make_rig(spec)

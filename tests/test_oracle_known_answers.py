@@ -256,6 +256,52 @@ def test_channel_sampling_paths(oracle32):
     assert rq.world.reshape(3, 4, 4)[2, 3, :3].tolist() == [2.75, 2.75, 2.75]
 
 
+def test_weights_channel_known_answers(oracle32):
+    """glTF "weights" channels (SKINRT_PATH_WEIGHTS; the reference's loader: todo!(), loader/gltf/mod.rs:1312):
+    the channel's sample replaces the instance's morph weights, component by component with Interpolate::linear /
+    cubic_spline (animation.rs:51-63) and the a4 key rule; instances on a clip without one keep the host's weights."""
+    t0 = MorphTarget(position=[[1, 0, 0]])
+    t1 = MorphTarget(position=[[0, 2, 0]])
+    lin = Channel(0, abi.PATH_WEIGHTS, abi.INTERP_LINEAR, [0, 2], [[0, 1], [4, 0]])
+    step = Channel(0, abi.PATH_WEIGHTS, abi.INTERP_STEP, [1, 2], [[1, 1], [3, 0.5]])
+    # per key (in, value, out), each [M]: component 0 is the known-answer Hermite case (vk 1, bk 2, vk1 3, ak1 4, td 2)
+    cub = Channel(0, abi.PATH_WEIGHTS, abi.INTERP_CUBICSPLINE, [0, 2],
+                  [[[9, 9], [1, 0], [2, 0]], [[4, 0], [3, 0], [9, 9]]])
+    none = Channel(0, abi.PATH_TRANSLATION, abi.INTERP_STEP, [0], [[0, 0, 5]])
+    rig = rig_of(parent=[-1], joint_node=(0,), pos=[(0, 0, 0)], targets=[t0, t1], clips=[[lin], [step], [cub], [none]],
+                 default_weights=[0.25, 0.25])
+    host = np.tile(np.array([[10.0, 10.0]], np.float32), (7, 1))
+    r = oracle32.evaluate(rig, tau=[0.5, 0.0, 1.5, 2.5, 1.0, 1.0, 3.0], clip_id=[0, 1, 1, 1, 2, 3, 0], morph_weights=host,
+                          cubic_quirk=0, want=("position", "key_index"))
+    p = r.position[:, 0]
+    assert p[0].tolist() == [1.0, 1.5, 0.0]      # linear u = .25: w = (0*.75 + 4*.25, 1*.75 + 0*.25)
+    assert p[1].tolist() == [1.0, 2.0, 0.0]      # before the first key: clamped to key 0
+    assert p[2].tolist() == [1.0, 2.0, 0.0]      # step inside the span: value[k]
+    assert p[3].tolist() == [3.0, 1.0, 0.0]      # after the last key: clamped to key 1
+    assert p[4].tolist() == [1.5, 0.0, 0.0]      # spec Hermite, u = .5
+    assert p[5].tolist() == [10.0, 20.0, 5.0]    # clip without a weights channel: the host's weights
+    assert p[6].tolist() == [4.0, 0.0, 0.0]      # linear, past the end
+    assert r.key_index[:, 0].tolist() == [0, 0, 0, 1, 0, 0, 1]
+    rq = oracle32.evaluate(rig, tau=[1.0], clip_id=[2], cubic_quirk=1, want=("position",))
+    assert rq.position[0, 0].tolist() == [2.75, 0.0, 0.0]   # t2 = t^3 as written (animation.rs:57)
+    # rest pose (clip id out of range): no channel applies, host weights / defaults
+    r0 = oracle32.evaluate(rig, tau=[0.5], clip_id=[0xFFFFFFFF], want=("position",))
+    assert r0.position[0, 0].tolist() == [0.25, 0.5, 0.0]
+
+
+def test_weights_channel_leaves_a_matrix_node_a_matrix(oracle32):
+    # a sheared matrix cannot survive to_scale_rotation_translation: if the weights channel counted as "animated"
+    # (node.rs:73-87) the node's world matrix would change
+    m = np.eye(4); m[0, 1] = 0.5; m[:3, 3] = [1, 2, 3]
+    cols = np.ascontiguousarray(m.T).reshape(1, 16)
+    t0 = MorphTarget(position=[[1, 0, 0]])
+    ch = Channel(0, abi.PATH_WEIGHTS, abi.INTERP_STEP, [0], [[2.0]])
+    rig = rig_of(parent=[-1], joint_node=(0,), pos=[(0, 0, 0)], targets=[t0], clips=[[ch]], matrix=cols, has_matrix=np.array([1], np.uint8))
+    r = oracle32.evaluate(rig, tau=[0.0], clip_id=[0], want=("world", "position"))
+    assert r.world.reshape(4, 4).T.tolist() == m.tolist()
+    assert r.position[0, 0].tolist() == [3.0, 2.0, 3.0]    # M * (2, 0, 0, 1): x = 2 + 1, y = 2, z = 3
+
+
 def test_matrix_node_static_and_animated(oracle32):
     # a Matrix node keeps its matrix unless animated; animated -> decomposed once, channel replaces T
     m = oracle32.trs_to_mat4([1, 2, 3], [0, 0, 1, 0], [2, 2, 2]).astype(np.float32)
