@@ -1,0 +1,200 @@
+//! Safe host side of libskinrt for the reference's Rust code: what `Entity::render`
+//! (crates/renderer/src/client/entity/mod.rs:34) calls per frame, and the one-time upload of the loader
+//! output.  Mirrors `renderer_amd/host/skinned_scene.hpp` (C++, compiled and tested in this repository) and
+//! `renderer_amd/api.py` (Python, used by the tests and the bench).  Source only here: no cargo in the build image.
+//!
+//! There is no CPU fallback: `Context::new` fails with `SKINRT_E_DEVICE` without an MI355X.
+pub mod flatten;
+
+use std::ffi::CStr;
+use std::marker::PhantomData;
+use std::ptr;
+
+use renderer_asset::animation::AnimationAsset;
+use renderer_asset::scene::SceneAsset;
+pub use skinrt_sys as sys;
+
+#[derive(Debug, Clone)]
+pub struct Error {
+    pub code: i32,
+    pub message: String,
+}
+
+impl Error {
+    pub fn new(code: i32, message: &str) -> Self {
+        Self { code, message: message.to_string() }
+    }
+    fn last(code: i32) -> Self {
+        let message = unsafe { CStr::from_ptr(sys::skinrt_last_error()) }.to_string_lossy().into_owned();
+        Self { code, message }
+    }
+}
+
+impl std::fmt::Display for Error {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        write!(f, "skinrt error {}: {}", self.code, self.message)
+    }
+}
+impl std::error::Error for Error {}
+
+fn check(rc: i32) -> Result<(), Error> {
+    if rc == sys::SKINRT_OK { Ok(()) } else { Err(Error::last(rc)) }
+}
+
+/// `SkinMatrix` exactly as the reference uploads it (crates/renderer/src/renderer/uniform/skin.rs:12-17): 112 bytes.
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct SkinMatrix {
+    pub transform: [[f32; 4]; 4],
+    pub normal: [[f32; 4]; 3],
+}
+
+/// One HIP device + stream.  Drive a context and its crowds from one thread (the reference renders from one thread,
+/// crates/renderer/src/state.rs:236).
+pub struct Context {
+    raw: *mut sys::skinrt_ctx,
+}
+
+impl Context {
+    pub fn new(device: i32) -> Result<Self, Error> {
+        Self::with_config(sys::skinrt_config { device, cubic_quirk: 1, ..Default::default() })
+    }
+    pub fn with_config(mut config: sys::skinrt_config) -> Result<Self, Error> {
+        config.struct_size = std::mem::size_of::<sys::skinrt_config>() as u32;
+        let mut raw = ptr::null_mut();
+        check(unsafe { sys::skinrt_init(&config, &mut raw) })?;
+        Ok(Self { raw })
+    }
+    pub fn synchronize(&self) -> Result<(), Error> {
+        check(unsafe { sys::skinrt_synchronize(self.raw) })
+    }
+    /// Validate, compile and upload the loader output of one model (renderer-asset/src/loader/gltf/mod.rs:199).
+    pub fn upload(&self, scenes: &[SceneAsset], animations: &[AnimationAsset]) -> Result<Rig<'_>, Error> {
+        let flat = flatten::flatten(scenes, animations, None)?;
+        self.upload_flat(&flat)
+    }
+    pub fn upload_flat(&self, flat: &flatten::FlatRig) -> Result<Rig<'_>, Error> {
+        let d = flatten::RigDesc::new(flat);
+        let mut raw = ptr::null_mut();
+        check(unsafe { sys::skinrt_upload_rig(self.raw, &d.desc, &mut raw) })?;
+        let mut info = sys::skinrt_rig_info::default();
+        check(unsafe { sys::skinrt_get_rig_info(raw, &mut info) })?;
+        Ok(Rig { raw, info, clip_length: flat.clip_length.clone(), _ctx: PhantomData })
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        unsafe { sys::skinrt_destroy_ctx(self.raw) };
+    }
+}
+
+pub struct Rig<'c> {
+    raw: *mut sys::skinrt_rig,
+    pub info: sys::skinrt_rig_info,
+    pub clip_length: Vec<f32>,
+    _ctx: PhantomData<&'c Context>,
+}
+
+impl<'c> Rig<'c> {
+    /// `instances` copies of this rig (one `SkinUniformBuffer` per entity in the reference, uniform/skin.rs:39-57).
+    pub fn crowd(&self, ctx: &'c Context, instances: u32) -> Result<Crowd<'_>, Error> {
+        let mut raw = ptr::null_mut();
+        check(unsafe { sys::skinrt_create_crowd(ctx.raw, self.raw, instances, &mut raw) })?;
+        Ok(Crowd { raw, ctx: ctx.raw, instances, joints: self.info.joint_count, vertices: self.info.vertex_count,
+                   targets: self.info.target_count, _rig: PhantomData })
+    }
+}
+
+impl Drop for Rig<'_> {
+    fn drop(&mut self) {
+        unsafe { sys::skinrt_destroy_rig(self.raw) };
+    }
+}
+
+pub struct Crowd<'r> {
+    raw: *mut sys::skinrt_crowd,
+    ctx: *mut sys::skinrt_ctx,
+    instances: u32,
+    joints: u32,
+    vertices: u32,
+    targets: u32,
+    _rig: PhantomData<&'r ()>,
+}
+
+impl Crowd<'_> {
+    /// Per-instance clock (seconds, wrapped by the caller) and clip; `clip_id = None`: clip 0 for everyone.
+    pub fn set_clocks(&mut self, tau: &[f32], clip_id: Option<&[u32]>) -> Result<(), Error> {
+        if tau.len() != self.instances as usize || clip_id.map(|c| c.len() != tau.len()).unwrap_or(false) {
+            return Err(Error::new(sys::SKINRT_E_INVALID, "one clock (and clip) per instance"));
+        }
+        check(unsafe { sys::skinrt_set_clocks(self.raw, tau.as_ptr(), clip_id.map(|c| c.as_ptr()).unwrap_or(ptr::null())) })
+    }
+    /// `weights[instance][target]`; `None` restores the rig's defaults (NodeAsset.weights / MeshAsset.weights).
+    pub fn set_morph_weights(&mut self, weights: Option<&[f32]>) -> Result<(), Error> {
+        if let Some(w) = weights {
+            if w.len() != self.instances as usize * self.targets as usize {
+                return Err(Error::new(sys::SKINRT_E_INVALID, "instances x targets weights expected"));
+            }
+        }
+        check(unsafe { sys::skinrt_set_morph_weights(self.raw, weights.map(|w| w.as_ptr()).unwrap_or(ptr::null())) })
+    }
+    /// Column-major `Mat4::to_cols_array` per instance (InstanceUniformBuffer.transform, uniform/transform.rs:17-20).
+    pub fn set_root_transforms(&mut self, matrices: Option<&[[f32; 16]]>) -> Result<(), Error> {
+        if let Some(m) = matrices {
+            if m.len() != self.instances as usize {
+                return Err(Error::new(sys::SKINRT_E_INVALID, "one root matrix per instance"));
+            }
+        }
+        check(unsafe { sys::skinrt_set_root_transforms(self.raw, matrices.map(|m| m.as_ptr().cast()).unwrap_or(ptr::null())) })
+    }
+    /// Enqueue the stages (asynchronous): the body `Entity::render` leaves empty.
+    pub fn evaluate(&mut self, stages: u32) -> Result<(), Error> {
+        check(unsafe { sys::skinrt_evaluate(self.raw, stages) })
+    }
+    pub fn synchronize(&self) -> Result<(), Error> {
+        check(unsafe { sys::skinrt_synchronize(self.ctx) })
+    }
+    /// `[SkinMatrix; 128]` of one instance, as `SkinUniformBuffer::update` builds it (uniform/skin.rs:41-50, :59-71).
+    pub fn skin_uniform(&self, instance: u32) -> Result<Box<[SkinMatrix; 128]>, Error> {
+        let mut out = Box::new([SkinMatrix { transform: [[0.0; 4]; 4], normal: [[0.0; 4]; 3] }; 128]);
+        check(unsafe { sys::skinrt_export_skin_uniform(self.raw, instance, out.as_mut_ptr().cast()) })?;
+        Ok(out)
+    }
+    /// Device pointers to the skinned positions / normals / tangents (`[instance][vertex][3]` f32 each), for a
+    /// storage-buffer vertex pull or an interop import; valid until the crowd is dropped.
+    pub fn device_outputs(&self) -> Result<[*mut f32; 3], Error> {
+        let mut p = [ptr::null_mut::<f32>(); 3];
+        let mut n = 0u64;
+        check(unsafe { sys::skinrt_get_positions(self.raw, &mut p[0], &mut n) })?;
+        check(unsafe { sys::skinrt_get_normals(self.raw, &mut p[1], &mut n) })?;
+        check(unsafe { sys::skinrt_get_tangents(self.raw, &mut p[2], &mut n) })?;
+        Ok(p)
+    }
+    /// Per-instance bounds `[min xyz, max xyz]`, downloaded.
+    pub fn aabbs(&self) -> Result<Vec<[f32; 6]>, Error> {
+        let mut dev = ptr::null_mut::<f32>();
+        let mut n = 0u64;
+        check(unsafe { sys::skinrt_get_aabbs(self.raw, &mut dev, &mut n) })?;
+        let mut out = vec![[0.0f32; 6]; self.instances as usize];
+        check(unsafe { sys::skinrt_download(self.ctx, dev.cast(), out.as_mut_ptr().cast(), n * 4) })?;
+        Ok(out)
+    }
+    /// `TextureSkinVertex` records (68 bytes each, buffer/vertex.rs:82-91) of instances `first .. first + count`, written
+    /// by one kernel into device memory the caller owns (16-byte aligned, `count * vertices * 68` bytes).
+    ///
+    /// # Safety
+    /// `dev_dst` and `dev_tex_coords` (`[vertex][2]` f32, or null = zeros) must be valid device pointers of those sizes.
+    pub unsafe fn texture_skin_vertices_device(&self, first: u32, count: u32, dev_tex_coords: *const f32, dev_dst: *mut u8) -> Result<(), Error> {
+        check(sys::skinrt_export_interleaved_device(self.raw, first, count, sys::SKINRT_LAYOUT_TEXTURE_SKIN, dev_tex_coords, dev_dst.cast()))
+    }
+    pub fn instances(&self) -> u32 { self.instances }
+    pub fn joints(&self) -> u32 { self.joints }
+    pub fn vertices(&self) -> u32 { self.vertices }
+}
+
+impl Drop for Crowd<'_> {
+    fn drop(&mut self) {
+        unsafe { sys::skinrt_destroy_crowd(self.raw) };
+    }
+}
