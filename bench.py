@@ -170,6 +170,9 @@ def main():
     torch = None
     rccl_ranks = 1
     if launched:
+        # RCCL prints a version banner on stdout at NCCL_DEBUG=VERSION: keep stdout to the one JSON line
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

@@ -178,6 +178,8 @@ extern "C" {
     pub fn skinrt_destroy_crowd(crowd: *mut skinrt_crowd) -> c_int;
     pub fn skinrt_get_output_placement(crowd: *mut skinrt_crowd, out_info: *mut skinrt_placement_info) -> c_int;
 
+    pub fn skinrt_shard_range(instances: u32, rank: u32, world: u32, out_first: *mut u32, out_count: *mut u32) -> c_int;
+
     pub fn skinrt_set_clocks(crowd: *mut skinrt_crowd, tau: *const f32, clip_id: *const u32) -> c_int;
     pub fn skinrt_set_morph_weights(crowd: *mut skinrt_crowd, weights: *const f32) -> c_int;
     pub fn skinrt_set_root_transforms(crowd: *mut skinrt_crowd, matrices: *const f32) -> c_int;

@@ -253,6 +253,12 @@ SKINRT_API int skinrt_destroy_crowd(skinrt_crowd* crowd);
 /* Output-array placement chosen and measured at skinrt_create_crowd. No reference counterpart. */
 SKINRT_API int skinrt_get_output_placement(skinrt_crowd* crowd, skinrt_placement_info* out_info);
 
+/* Instance range [*out_first, *out_first + *out_count) of rank `rank` of `world` when `instances` are sharded
+ * over processes / GPUs (one ctx and one crowd per GPU, the rig replicated, no data-path collective: SURVEY.md
+ * §8e): contiguous ranges of ceil(instances / world), the last ones shorter or empty.  Pure function, no device.
+ * The same rule as renderer_amd/shard.py, for hosts that are not Python. No reference counterpart. */
+SKINRT_API int skinrt_shard_range(uint32_t instances, uint32_t rank, uint32_t world, uint32_t* out_first, uint32_t* out_count);
+
 /* ---- per-frame inputs ----------------------------------------------------------------- */
 
 /* Per-instance animation clock tau[I] (seconds, already wrapped by the caller) and clip

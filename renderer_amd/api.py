@@ -34,6 +34,7 @@ EXPORTS = [
     "skinrt_get_palette", "skinrt_get_world", "skinrt_get_keyframe_index", "skinrt_download",
     "skinrt_export_skin_uniform", "skinrt_export_interleaved", "skinrt_calculate_tangent",
     "skinrt_calculate_tangent_noalloc", "skinrt_export_skin_uniform_device", "skinrt_export_interleaved_device",
+    "skinrt_shard_range",
 ]
 
 
@@ -81,6 +82,7 @@ def load_library() -> C.CDLL:
         "skinrt_export_interleaved": [vp, C.c_uint32, C.c_uint32, vp, vp],
         "skinrt_export_skin_uniform_device": [vp, C.c_uint32, C.c_uint32, vp],
         "skinrt_export_interleaved_device": [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp],
+        "skinrt_shard_range": [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
         "skinrt_calculate_tangent": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(C.c_float)],
         "skinrt_calculate_tangent_noalloc": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp],
     }
@@ -112,6 +114,13 @@ def make_config(device: int = 0, cubic_quirk: int = 1, normalize_outputs: int = 
     cfg.skin_path = skin_path
     cfg.output_placement = output_placement
     return cfg
+
+
+def shard_range(instances: int, rank: int, world: int) -> Tuple[int, int]:
+    """(first, count) of rank's instance range — the C ABI's rule (skinrt_shard_range)."""
+    lo, n = C.c_uint32(), C.c_uint32()
+    _check(load_library().skinrt_shard_range(instances, rank, world, C.byref(lo), C.byref(n)))
+    return int(lo.value), int(n.value)
 
 
 def validate_rig(rig: RigData, config: Optional[Config] = None) -> RigInfo:

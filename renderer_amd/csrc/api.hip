@@ -73,7 +73,7 @@ struct skinrt_crowd {
     skinrt_ctx* ctx = nullptr;
     skinrt_rig* rig = nullptr;
     uint32_t I = 0;
-    DevBuf tau, clip, mw, mw_eff, root, world, palette, keyidx, pos, nrm, tan, aabb_part, aabb, fix, amask;
+    DevBuf tau, clip, mw, mw_eff, local_t, root, world, palette, keyidx, pos, nrm, tan, aabb_part, aabb, fix, amask;
     bool has_root = false;
     SkinPlan plan{};
     PosePath pose_path = kPoseWave;
@@ -341,7 +341,7 @@ int skinrt_destroy_crowd(skinrt_crowd* c) {
         (void)hipSetDevice(c->ctx->cfg.device);
         (void)hipStreamSynchronize(c->ctx->stream);
     }
-    for (DevBuf* b : {&c->tau, &c->clip, &c->mw, &c->mw_eff, &c->root, &c->world, &c->palette, &c->keyidx, &c->pos, &c->nrm,
+    for (DevBuf* b : {&c->tau, &c->clip, &c->mw, &c->mw_eff, &c->local_t, &c->root, &c->world, &c->palette, &c->keyidx, &c->pos, &c->nrm,
                       &c->tan, &c->aabb_part, &c->aabb, &c->fix, &c->amask})
         b->release();
     for (auto& e : c->ev)
@@ -387,6 +387,15 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
         c->pos.p = p; c->nrm.p = n; c->tan.p = t;
         c->pos.bytes = c->nrm.bytes = c->tan.bytes = out_bytes;
     }
+    // sampled local matrices [N][I][12] of the lane-per-instance channel sampling (k_sample_nodes); allocated after the
+    // output arrays so that their steering sees the same free memory with and without it
+    if (h.clips && !(std::getenv("SKINRT_POSE_PRE") && std::atoi(std::getenv("SKINRT_POSE_PRE")) == 0)) {
+        if (c->local_t.alloc(I * h.N * 48) != hipSuccess) {
+            (void)hipGetLastError();
+            skinrt_destroy_crowd(c);
+            return fail(SKINRT_E_NOMEM, "hipMalloc of the sampled local matrices failed");
+        }
+    }
     for (int k = 0; k < 6; ++k) {
         hipEvent_t& e = c->ev[k];
         if ((k < 4 ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming)) != hipSuccess) {
@@ -420,6 +429,17 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
     } else if (ctx->cfg.pose_path == 2) c->pose_path = kPoseSplit;
     else c->pose_path = (fits && h.levels <= 256) ? kPoseWave : kPoseSplit;
     *out_crowd = c;
+    return SKINRT_OK;
+}
+
+int skinrt_shard_range(uint32_t instances, uint32_t rank, uint32_t world, uint32_t* out_first, uint32_t* out_count) {
+    if (!out_first || !out_count) return fail(SKINRT_E_INVALID, "skinrt_shard_range: NULL argument");
+    if (world == 0 || rank >= world) return fail(SKINRT_E_RANGE, "rank must be below world");
+    const uint64_t per = ((uint64_t)instances + world - 1) / world;
+    const uint64_t lo = std::min<uint64_t>(instances, (uint64_t)rank * per);
+    const uint64_t hi = std::min<uint64_t>(instances, lo + per);
+    *out_first = (uint32_t)lo;
+    *out_count = (uint32_t)(hi - lo);
     return SKINRT_OK;
 }
 
@@ -483,7 +503,7 @@ int skinrt_evaluate(skinrt_crowd* c, uint32_t mask) {
     const CrowdDev cr = c->dev();
     HIP_TRY(hipEventRecord(c->ev[0], s));
     if (mask & SKINRT_STAGE_POSE) {
-        HIP_TRY(launch_pose(rig, cr, c->ctx->cfg.cubic_quirk ? 1u : 0u, c->pose_path, s));
+        HIP_TRY(launch_pose(rig, cr, c->ctx->cfg.cubic_quirk ? 1u : 0u, c->pose_path, c->local_t.as<float>(), s));
         if (c->mw_eff.p) HIP_TRY(launch_sample_weights(rig, cr, c->mw_eff.as<float>(), c->ctx->cfg.cubic_quirk ? 1u : 0u, s));
     }
     HIP_TRY(hipEventRecord(c->ev[1], s));

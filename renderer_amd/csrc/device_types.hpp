@@ -104,7 +104,8 @@ struct SkinConcurrency {
 enum PosePath : uint32_t { kPoseWave = 0, kPoseSplit = 1 };
 
 // kernels_pose.hip
-hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t cubic_quirk, PosePath path, hipStream_t s);
+// local_t: [N][I][12] scratch for the lane-per-instance channel sampling, or nullptr (sampling inside the pose kernels)
+hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t cubic_quirk, PosePath path, float* local_t, hipStream_t s);
 hipError_t launch_sample_weights(const RigDev& rig, const CrowdDev& cr, float* mw_out, uint32_t quirk, hipStream_t s);
 // kernels_skin.hip
 hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s, const SkinConcurrency& conc);

@@ -195,18 +195,26 @@ __device__ __forceinline__ void clear_unused_keys(const RigDev& rig, uint32_t cl
 }
 
 // ---- wavefront-per-instance ------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_pose_wave(const RigDev rig, const CrowdDev cr, const uint32_t quirk) {
+// local_t != nullptr: the local matrices were sampled by k_sample_nodes (lane = instance; see there) and are
+// read from local_t[node][instance][12]; else they are sampled here, lane = node.
+__global__ __launch_bounds__(64) void k_pose_wave(const RigDev rig, const CrowdDev cr, const uint32_t quirk, const float* __restrict__ local_t) {
     extern __shared__ float4 node_s[];  // [N][3] rows
     const uint32_t i = blockIdx.x, lane = threadIdx.x;
-    const uint32_t clip = cr.clip[i];
-    const bool has_clip = clip < rig.clips;
-    const float tau = cr.tau[i];
-    uint32_t* keyrow = cr.keyidx + (size_t)i * rig.Cmax;
-    clear_unused_keys(rig, clip, has_clip, keyrow, lane, 64);
-
-    for (uint32_t n = lane; n < rig.N; n += 64) {
-        const Rows l = node_local(rig, clip, has_clip, n, tau, quirk, keyrow);
-        node_s[n * 3 + 0] = l.r0; node_s[n * 3 + 1] = l.r1; node_s[n * 3 + 2] = l.r2;
+    if (local_t) {
+        for (uint32_t n = lane; n < rig.N; n += 64) {
+            const Rows l = load_rows(local_t + ((size_t)n * cr.I + i) * 12);
+            node_s[n * 3 + 0] = l.r0; node_s[n * 3 + 1] = l.r1; node_s[n * 3 + 2] = l.r2;
+        }
+    } else {
+        const uint32_t clip = cr.clip[i];
+        const bool has_clip = clip < rig.clips;
+        const float tau = cr.tau[i];
+        uint32_t* keyrow = cr.keyidx + (size_t)i * rig.Cmax;
+        clear_unused_keys(rig, clip, has_clip, keyrow, lane, 64);
+        for (uint32_t n = lane; n < rig.N; n += 64) {
+            const Rows l = node_local(rig, clip, has_clip, n, tau, quirk, keyrow);
+            node_s[n * 3 + 0] = l.r0; node_s[n * 3 + 1] = l.r1; node_s[n * 3 + 2] = l.r2;
+        }
     }
     __syncthreads();
     Rows root;
@@ -233,6 +241,26 @@ __global__ __launch_bounds__(64) void k_pose_wave(const RigDev rig, const CrowdD
         w.r0 = node_s[n * 3 + 0]; w.r1 = node_s[n * 3 + 1]; w.r2 = node_s[n * 3 + 2];
         palette_entry(w, load_rows(rig.ibm + (size_t)j * 12), cr.palette + ((size_t)i * rig.J + j) * kPalFloats);
     }
+}
+
+// ---- channel sampling with lane = instance ----------------------------------------------------
+// Thread = (node n, instance i), i fastest: the 64 lanes of a wave sample the SAME node's channels for 64
+// instances.  When they play the same clip (the common case) every table load of the wave — channel record, key
+// times of the binary search, key values — falls into the same one or two cache lines, where the lane = node
+// mapping touched 64 different lines per load (C3: 619 such loads per wave, the pose stage's largest cost).  The
+// arithmetic is node_local()'s, so key indices and matrices are bit-identical.  Output: local_t[n][i][12], 48
+// contiguous bytes per lane = fully coalesced; the consumers read it back with a stride (k_pose_wave,
+// k_propagate_quad), which costs less than scattered partial-line writes would.
+__global__ __launch_bounds__(256) void k_sample_nodes(const RigDev rig, const CrowdDev cr, const uint32_t quirk, float* __restrict__ local_t,
+                                                      const uint32_t iblocks) {
+    const uint32_t n = blockIdx.x / iblocks, i = (blockIdx.x - n * iblocks) * 256 + threadIdx.x;
+    if (n >= rig.N || i >= cr.I) return;
+    const uint32_t clip = cr.clip[i];
+    const bool has_clip = clip < rig.clips;
+    uint32_t* keyrow = cr.keyidx + (size_t)i * rig.Cmax;
+    if (n == 0) clear_unused_keys(rig, clip, has_clip, keyrow, 0, 1);
+    const Rows l = node_local(rig, clip, has_clip, n, cr.tau[i], quirk, keyrow);
+    store_rows(local_t + ((size_t)n * cr.I + i) * 12, l);
 }
 
 // ---- split path -----------------------------------------------------------------------------
@@ -262,7 +290,7 @@ __device__ __forceinline__ float quad_bcast(float v) {
 
 constexpr int kPropChunk = 8;  // nodes whose local columns are in registers ahead of the chain
 
-__global__ __launch_bounds__(64) void k_propagate_quad(const RigDev rig, const CrowdDev cr) {
+__global__ __launch_bounds__(64) void k_propagate_quad(const RigDev rig, const CrowdDev cr, const float* __restrict__ local_t) {
     const uint32_t lane = threadIdx.x, e = lane & 15;
     const uint32_t i = blockIdx.x * 4 + (lane >> 4);
     const bool act = i < cr.I && e < 12;
@@ -278,7 +306,8 @@ __global__ __launch_bounds__(64) void k_propagate_quad(const RigDev rig, const C
         for (int d = 0; d < kPropChunk; ++d) {
             const uint32_t n = base + d;
             const bool ok = act && n < N;
-            const float* q = w + (size_t)n * 12 + c;
+            // locals: written in place by k_sample_local, or local_t[n][i][12] from k_sample_nodes
+            const float* q = local_t ? local_t + ((size_t)n * cr.I + (act ? i : 0)) * 12 + c : w + (size_t)n * 12 + c;
             a0[d] = ok ? q[0] : 0.0f;
             a1[d] = ok ? q[4] : 0.0f;
             a2[d] = ok ? q[8] : 0.0f;
@@ -394,16 +423,21 @@ hipError_t launch_sample_weights(const RigDev& rig, const CrowdDev& cr, float* m
     return hipGetLastError();
 }
 
-hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t quirk, PosePath path, hipStream_t s) {
+hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t quirk, PosePath path, float* local_t, hipStream_t s) {
     if (cr.I == 0) return hipSuccess;
+    if (local_t) {
+        const uint32_t iblocks = (cr.I + 255) / 256;
+        if ((uint64_t)iblocks * rig.N > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_sample_nodes, dim3(iblocks * rig.N), dim3(256), 0, s, rig, cr, quirk, local_t, iblocks);
+    }
     if (path == kPoseWave) {
         const size_t lds = (size_t)rig.N * 48;
-        hipLaunchKernelGGL(k_pose_wave, dim3(cr.I), dim3(64), lds, s, rig, cr, quirk);
+        hipLaunchKernelGGL(k_pose_wave, dim3(cr.I), dim3(64), lds, s, rig, cr, quirk, local_t);
         return hipGetLastError();
     }
     const uint64_t in = (uint64_t)cr.I * rig.N;
-    hipLaunchKernelGGL(k_sample_local, dim3((uint32_t)((in + 255) / 256)), dim3(256), 0, s, rig, cr, quirk);
-    hipLaunchKernelGGL(k_propagate_quad, dim3((cr.I + 3) / 4), dim3(64), 0, s, rig, cr);
+    if (!local_t) hipLaunchKernelGGL(k_sample_local, dim3((uint32_t)((in + 255) / 256)), dim3(256), 0, s, rig, cr, quirk);
+    hipLaunchKernelGGL(k_propagate_quad, dim3((cr.I + 3) / 4), dim3(64), 0, s, rig, cr, local_t);
     if (rig.J) {
         const uint64_t ij = (uint64_t)cr.I * rig.J;
         hipLaunchKernelGGL(k_palette, dim3((uint32_t)((ij + 255) / 256)), dim3(256), 0, s, rig, cr);

@@ -28,6 +28,17 @@ def test_shard_ranges_partition_the_crowd(instances, world):
     assert seen == list(range(instances))
 
 
+@pytest.mark.parametrize("instances,world", [(10, 2), (11, 2), (1, 2), (0, 4), (100000, 8), (7, 8), (9, 8), (4000000000, 3)])
+def test_c_abi_shard_rule_is_the_python_rule(instances, world):
+    from renderer_amd import abi, api
+    for r in range(world):
+        lo, hi = shard.shard_range(instances, r, world)
+        assert api.shard_range(instances, r, world) == (lo, hi - lo)
+    with pytest.raises(api.SkinrtError) as e:
+        api.shard_range(10, 2, 2)
+    assert e.value.code == abi.E_RANGE
+
+
 def test_crowd_shards_draw_the_same_streams_as_the_whole_crowd():
     spec = synth.tiny_spec(seed=21)
     rig = synth.make_rig(spec)
