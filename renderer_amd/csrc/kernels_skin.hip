@@ -774,25 +774,52 @@ __global__ __launch_bounds__(256) void k_active_mask(const CrowdDev cr, uint32_t
     if (lane == 0) cr.amask[g] = b;
 }
 
-// Work lists of the fix role, built before the skin kernel starts so that both roles can run in ONE launch:
-// thread = (tile, instance); slow pairs are appended to the tile's list (one atomicAdd per wave).
-__global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdDev cr, uint32_t chunks, uint32_t words) {
-    const uint32_t tile = blockIdx.x / chunks, inst = (blockIdx.x - tile * chunks) * 256 + threadIdx.x;
+// Work lists of k_skin_fix, built before the skin kernels start so that both can run at the same time.
+// Block = (tile, slice of the instance range); a thread classifies one instance per round of 256.  The round's slow
+// instances are compacted inside the block (ballot + per-wave totals in LDS); with one slice per tile (`slices` == 1)
+// the list position is a running count kept by the block and the list is in instance order; otherwise the block
+// reserves the round's entries with ONE atomicAdd.  (One atomicAdd per wave — 160 on the same counter for C3 — made
+// this kernel take 0.10 ms; tiles whose count the kernel does not touch keep the zero of the launch's memset.)
+// The final count is an atomicAdd too, one per tile, and that is not an optimisation left undone: written with a
+// plain store, counts were LOST on the GPU (C5: 2-76 tiles of an instance unserved, different ones every run).
+// Neighbouring tiles' counts share a 128-byte line, their blocks run on different XCDs, and the memset before this
+// kernel has just written the whole line; a device-scope atomic is performed at the memory side and is not subject
+// to whichever L2 writes that line back last.
+__global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdDev cr, uint32_t slices, uint32_t words) {
+    __shared__ uint32_t wave_n[4];
+    __shared__ uint32_t round_base;
+    const uint32_t tile = blockIdx.x / slices, slice = blockIdx.x - tile * slices;
     if (tile >= rig.T || rig.tile_lds[tile] != 2) return;
     const uint32_t pbeg = rig.tile_pair_start[tile], np = rig.tile_pair_start[tile + 1] - pbeg;
     if (np == 0) return;
-    const uint32_t lane = threadIdx.x & 63;
-    bool slow = false;
-    if (inst < cr.I) slow = classify_pairs(rig.pairs + pbeg, np, cr.amask + (size_t)inst * words, words, cr.mw + (size_t)inst * rig.M).slow;
-    const uint64_t bslow = __ballot(slow);
-    if (!bslow) return;  // wave-uniform
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(cr.fix + tile, (uint32_t)__popcll(bslow));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (slow) {
-        const uint32_t e = base + (uint32_t)__popcll(bslow & ((1ull << lane) - 1ull));
-        if (e < cr.I) cr.fix_inst[(size_t)tile * cr.I + e] = inst;  // (an instance is listed at most once per tile)
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t per = ((cr.I + slices - 1) / slices + 255) / 256 * 256;  // instances per slice, whole rounds
+    const uint32_t i0 = slice * per, i1 = min(cr.I, i0 + per);
+    uint32_t running = 0;  // slices == 1: entries written so far
+    for (uint32_t r0 = i0; r0 < i1; r0 += 256) {
+        const uint32_t inst = r0 + tid;
+        bool slow = false;
+        if (inst < i1) slow = classify_pairs(rig.pairs + pbeg, np, cr.amask + (size_t)inst * words, words, cr.mw + (size_t)inst * rig.M).slow;
+        const uint64_t bslow = __ballot(slow);
+        if (lane == 0) wave_n[wave] = (uint32_t)__popcll(bslow);
+        __syncthreads();
+        const uint32_t n0 = wave_n[0], n1 = wave_n[1], n2 = wave_n[2], n3 = wave_n[3];
+        const uint32_t total = n0 + n1 + n2 + n3;
+        uint32_t base = running;
+        if (slices > 1) {
+            if (tid == 0 && total) round_base = atomicAdd(cr.fix + tile, total);
+            __syncthreads();
+            base = round_base;
+        }
+        if (slow) {
+            const uint32_t before = (wave > 0 ? n0 : 0u) + (wave > 1 ? n1 : 0u) + (wave > 2 ? n2 : 0u);
+            const uint32_t e = base + before + (uint32_t)__popcll(bslow & ((1ull << lane) - 1ull));
+            if (e < cr.I) cr.fix_inst[(size_t)tile * cr.I + e] = inst;  // (an instance is listed at most once per tile)
+        }
+        running += total;
+        __syncthreads();  // wave_n / round_base are rewritten in the next round
     }
+    if (slices == 1 && tid == 0 && running) atomicAdd(cr.fix + tile, running);
 }
 
 // fix_role — the (tile, instance) pairs the self-staging role leaves out (k_classify lists them): instances with three or more active
@@ -1340,12 +1367,13 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         if (cr.fix) {
             e = hipMemsetAsync(cr.fix, 0, (size_t)rig.T * 4, s);  // empty work lists
             if (e != hipSuccess) return e;
-            const uint32_t chunks = (cr.I + 255) / 256;
-            if ((uint64_t)rig.T * chunks > 0x7fffffffull) return hipErrorInvalidValue;
+            // one block per tile walks all instances; crowds beyond 16k instances are cut into up to 16 slices per tile
+            const uint32_t slices = std::min(16u, (cr.I + 16383) / 16384);
+            if ((uint64_t)rig.T * slices > 0x7fffffffull) return hipErrorInvalidValue;
             const uint32_t words = (rig.M + 63) / 64;
             if (!cr.amask || (uint64_t)cr.I * words > 0x7fffffffull) return hipErrorInvalidValue;
             hipLaunchKernelGGL(k_active_mask, dim3((cr.I * words + 3) / 4), dim3(256), 0, s, cr, rig.M, words);
-            hipLaunchKernelGGL(k_classify, dim3(rig.T * chunks), dim3(256), 0, s, rig, cr, chunks, words);
+            hipLaunchKernelGGL(k_classify, dim3(rig.T * slices), dim3(256), 0, s, rig, cr, slices, words);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             if (side && (e = hipEventRecord(conc.fork, s)) != hipSuccess) return e;  // the lists are complete here

@@ -212,6 +212,35 @@ def test_stages_run_separately_give_the_same_frame(oracle32):
         c.close(); r.close()
 
 
+def test_crowd_reused_over_frames(oracle32):
+    """One crowd, several frames with different clocks, clips and morph weights: every frame must equal the oracle
+    run on that frame's inputs alone — nothing of the previous frame (work lists and their counts, active-target
+    masks, bounds partials, sampled locals) may leak into the next.  The morph schedule changes the work lists from
+    full (every instance has many active targets) to sparse to empty."""
+    spec = synth.scaled(synth.CONFIGS["c3"], verts=5000, targets=12, keys=6)
+    rig = synth.make_rig(spec)
+    inst = 700
+    rng = np.random.default_rng(77)
+    frames = []
+    for f, frac in enumerate((1.0, 0.3, 0.0, 0.6)):
+        crowd = synth.make_crowd(synth.scaled(spec, seed=spec.seed + f), rig, instances=inst)
+        mw = rng.uniform(-1, 1, size=crowd.morph_weights.shape).astype(np.float32)
+        mw[rng.uniform(size=mw.shape) >= frac] = 0.0
+        crowd.morph_weights = mw
+        frames.append(crowd)
+    with api.Context(exact_arithmetic=1) as ctx:
+        r = api.Rig(ctx, rig)
+        c = api.Crowd(ctx, r, inst)
+        for f, crowd in enumerate(frames):
+            c.set_clocks(crowd.tau, crowd.clip_id)
+            c.set_morph_weights(crowd.morph_weights)
+            c.evaluate(sync=True)
+            got = {"world": c.world(), "palette": c.palette(), "key_index": c.keyframe_index(), "position": c.positions(),
+                   "normal": c.normals(), "tangent": c.tangents(), "aabb": c.aabbs()}
+            _check_all(got, run_oracle(oracle32, rig, crowd), exact_skin=True, tag=f"frame {f}:")
+        c.close(); r.close()
+
+
 def test_scattered_joints_use_global_palette_path(oracle32):
     """Worst-case locality: influences uniform over 300 joints -> tile joint lists exceed the LDS
     cap and the kernel gathers the palette from L2 instead.  Joint gathers must stay exact."""
