@@ -775,51 +775,56 @@ __global__ __launch_bounds__(256) void k_active_mask(const CrowdDev cr, uint32_t
 }
 
 // Work lists of k_skin_fix, built before the skin kernels start so that both can run at the same time.
-// Block = (tile, slice of the instance range); a thread classifies one instance per round of 256.  The round's slow
-// instances are compacted inside the block (ballot + per-wave totals in LDS); with one slice per tile (`slices` == 1)
-// the list position is a running count kept by the block and the list is in instance order; otherwise the block
-// reserves the round's entries with ONE atomicAdd.  (One atomicAdd per wave — 160 on the same counter for C3 — made
-// this kernel take 0.10 ms; tiles whose count the kernel does not touch keep the zero of the launch's memset.)
-// The final count is an atomicAdd too, one per tile, and that is not an optimisation left undone: written with a
-// plain store, counts were LOST on the GPU (C5: 2-76 tiles of an instance unserved, different ones every run).
-// Neighbouring tiles' counts share a 128-byte line, their blocks run on different XCDs, and the memset before this
-// kernel has just written the whole line; a device-scope atomic is performed at the memory side and is not subject
-// to whichever L2 writes that line back last.
+// Block = (tile, slice of kClassifyRounds * 256 instances).  A thread classifies one instance per round; all rounds'
+// loads are in flight together (no barrier between rounds), the slow instances are compacted inside the block (ballot,
+// per-wave totals in LDS) and the block reserves its entries with ONE atomicAdd on the tile's count.  History: one
+// atomicAdd per wave (160 on the same counter for C3) took 0.10 ms; one block per tile walking all instances round by
+// round, 0.06 ms (40 dependent rounds); this form is bound by nothing in particular.
+// The count must be updated by an atomic even where a block is the tile's only writer: written with a plain store,
+// counts were LOST on the GPU (C5: 2-76 tiles of an instance unserved, different ones every run).  Neighbouring
+// tiles' counts share a 128-byte line, their blocks run on different XCDs, and the memset before this kernel has just
+// written the whole line; a device-scope atomic is performed at the memory side and is not subject to whichever L2
+// writes that line back last.  Tiles whose count the kernel does not touch keep the zero of the launch's memset.
+constexpr uint32_t kClassifyRounds = 8;
 __global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdDev cr, uint32_t slices, uint32_t words) {
-    __shared__ uint32_t wave_n[4];
-    __shared__ uint32_t round_base;
+    __shared__ uint32_t wave_n[kClassifyRounds * 4];  // [round][wave]
+    __shared__ uint32_t block_base;
     const uint32_t tile = blockIdx.x / slices, slice = blockIdx.x - tile * slices;
     if (tile >= rig.T || rig.tile_lds[tile] != 2) return;
     const uint32_t pbeg = rig.tile_pair_start[tile], np = rig.tile_pair_start[tile + 1] - pbeg;
     if (np == 0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t per = ((cr.I + slices - 1) / slices + 255) / 256 * 256;  // instances per slice, whole rounds
-    const uint32_t i0 = slice * per, i1 = min(cr.I, i0 + per);
-    uint32_t running = 0;  // slices == 1: entries written so far
-    for (uint32_t r0 = i0; r0 < i1; r0 += 256) {
-        const uint32_t inst = r0 + tid;
+    const uint32_t i0 = slice * (kClassifyRounds * 256u);
+    uint32_t mine = 0;                    // bit r: my instance of round r is slow
+    uint32_t rank[kClassifyRounds];       // its position among the wave's slow instances of that round
+#pragma unroll
+    for (uint32_t r = 0; r < kClassifyRounds; ++r) {
+        const uint32_t inst = i0 + r * 256u + tid;
         bool slow = false;
-        if (inst < i1) slow = classify_pairs(rig.pairs + pbeg, np, cr.amask + (size_t)inst * words, words, cr.mw + (size_t)inst * rig.M).slow;
+        if (inst < cr.I) slow = classify_pairs(rig.pairs + pbeg, np, cr.amask + (size_t)inst * words, words, cr.mw + (size_t)inst * rig.M).slow;
         const uint64_t bslow = __ballot(slow);
-        if (lane == 0) wave_n[wave] = (uint32_t)__popcll(bslow);
-        __syncthreads();
-        const uint32_t n0 = wave_n[0], n1 = wave_n[1], n2 = wave_n[2], n3 = wave_n[3];
-        const uint32_t total = n0 + n1 + n2 + n3;
-        uint32_t base = running;
-        if (slices > 1) {
-            if (tid == 0 && total) round_base = atomicAdd(cr.fix + tile, total);
-            __syncthreads();
-            base = round_base;
-        }
-        if (slow) {
-            const uint32_t before = (wave > 0 ? n0 : 0u) + (wave > 1 ? n1 : 0u) + (wave > 2 ? n2 : 0u);
-            const uint32_t e = base + before + (uint32_t)__popcll(bslow & ((1ull << lane) - 1ull));
-            if (e < cr.I) cr.fix_inst[(size_t)tile * cr.I + e] = inst;  // (an instance is listed at most once per tile)
-        }
-        running += total;
-        __syncthreads();  // wave_n / round_base are rewritten in the next round
+        if (lane == 0) wave_n[r * 4 + wave] = (uint32_t)__popcll(bslow);
+        rank[r] = (uint32_t)__popcll(bslow & ((1ull << lane) - 1ull));
+        if (slow) mine |= 1u << r;
     }
-    if (slices == 1 && tid == 0 && running) atomicAdd(cr.fix + tile, running);
+    __syncthreads();
+    uint32_t before[kClassifyRounds], total = 0;  // entries of the block that precede my wave's of round r
+#pragma unroll
+    for (uint32_t r = 0; r < kClassifyRounds; ++r) {
+        const uint4 n = *reinterpret_cast<const uint4*>(wave_n + r * 4);
+        before[r] = total + (wave > 0 ? n.x : 0u) + (wave > 1 ? n.y : 0u) + (wave > 2 ? n.z : 0u);
+        total += n.x + n.y + n.z + n.w;
+    }
+    if (total == 0) return;  // block-uniform
+    if (tid == 0) block_base = atomicAdd(cr.fix + tile, total);
+    __syncthreads();
+    const uint32_t base = block_base;
+#pragma unroll
+    for (uint32_t r = 0; r < kClassifyRounds; ++r)
+        if ((mine >> r) & 1u) {
+            const uint32_t e = base + before[r] + rank[r];
+            if (e < cr.I) cr.fix_inst[(size_t)tile * cr.I + e] = i0 + r * 256u + tid;  // (an instance is listed at most once per tile)
+        }
 }
 
 // fix_role — the (tile, instance) pairs the self-staging role leaves out (k_classify lists them): instances with three or more active
@@ -1367,8 +1372,7 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         if (cr.fix) {
             e = hipMemsetAsync(cr.fix, 0, (size_t)rig.T * 4, s);  // empty work lists
             if (e != hipSuccess) return e;
-            // one block per tile walks all instances; crowds beyond 16k instances are cut into up to 16 slices per tile
-            const uint32_t slices = std::min(16u, (cr.I + 16383) / 16384);
+            const uint32_t slices = (cr.I + kClassifyRounds * 256u - 1) / (kClassifyRounds * 256u);
             if ((uint64_t)rig.T * slices > 0x7fffffffull) return hipErrorInvalidValue;
             const uint32_t words = (rig.M + 63) / 64;
             if (!cr.amask || (uint64_t)cr.I * words > 0x7fffffffull) return hipErrorInvalidValue;
