@@ -149,7 +149,7 @@ pub struct skinrt_rig_info {
     pub exact_arithmetic: u32,
     pub bind_extent: f32,
     pub weight_channel_clips: u32,
-    pub reserved: u32,
+    pub skip_weight_sets: u32,
 }
 
 #[repr(C)]

@@ -205,7 +205,9 @@ typedef struct skinrt_rig_info {
     uint32_t exact_arithmetic;     /* 1: the skin stage runs contraction-free on this rig (skinrt_config.exact_arithmetic) */
     float bind_extent;             /* largest |translation component| over the inverse bind matrices */
     uint32_t weight_channel_clips; /* clips that carry a SKINRT_PATH_WEIGHTS channel */
-    uint32_t reserved;
+    /* 1: enough 64-vertex waves of the mesh have all-zero weights in the second weight set that the skin stage runs
+     *    the kernels which let such a wave stop after the first set (same results: the skipped terms are 0 * M) */
+    uint32_t skip_weight_sets;
 } skinrt_rig_info;
 
 /* What skinrt_create_crowd did with the output arrays and what it measured (all zero for small crowds

@@ -116,7 +116,7 @@ class RigInfo(C.Structure):
         ("max_tile_joints", C.c_uint32), ("lds_tiles", C.c_uint32), ("max_channels", C.c_uint32),
         ("morph_entries", C.c_uint64), ("device_bytes", C.c_uint64),
         ("exact_arithmetic", C.c_uint32), ("bind_extent", C.c_float),
-        ("weight_channel_clips", C.c_uint32), ("reserved", C.c_uint32),
+        ("weight_channel_clips", C.c_uint32), ("skip_weight_sets", C.c_uint32),
     ]
 
 

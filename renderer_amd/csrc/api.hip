@@ -177,6 +177,8 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
         p.range2 = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(r2, 1), kSkin2Range);
         p.ranges2 = I ? (I + p.range2 - 1) / p.range2 : 0;
         p.ranges_per_chunk2 = (std::max<uint32_t>(1, p.ranges2) + rcs - 1) / rcs;
+        p.interleave2 = (uint64_t)p.range2 * r.J * 96 <= (2u << 20) ? 1 : 0;  // a block range's palettes fit an XCD's L2 twice over
+        if (const char* ev = getenv("SKINRT_TILE_INTERLEAVE")) p.interleave2 = atoi(ev) ? 1 : 0;
     }
     p.exact = r.exact;  // skinrt_config.exact_arithmetic resolved per rig at compile time
     p.normalize = cfg.normalize_outputs ? 1 : 0;
@@ -308,6 +310,8 @@ int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig**
     d.N = h.N; d.J = h.J; d.V = h.V; d.K = h.K; d.M = h.M; d.clips = h.clips; d.Cmax = h.Cmax;
     d.levels = h.levels; d.T = h.T;
     d.weight_channel_clips = h.weight_channel_clips;
+    d.skip_sets = h.skip_sets ? 1u : 0u;
+    if (const char* ev = getenv("SKINRT_SKIP_SETS")) d.skip_sets = (h.K == 2 && atoi(ev) != 0) ? 1u : 0u;  // experiments (tools/exp_skip_sets.py)
     const float* defw = nullptr;
 #define UP(field) if ((rc = upload(r, h.field, &d.field)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
     UP(parent) UP(rest_trs) UP(rest_mat) UP(node_matrix) UP(level_start) UP(level_nodes) UP(node_chan)

@@ -35,6 +35,7 @@ struct RigDev {
     const uint32_t* tile_pair_start;
     const MorphPair* pairs;
     const float* mblock;
+    uint32_t skip_sets;  // CompiledRig::skip_sets
 };
 
 // Per-crowd state and outputs (HBM layout: DESIGN.md §3).
@@ -89,6 +90,7 @@ struct SkinPlan {
     uint32_t lds_bytes2;         // dynamic LDS per k_skin2 block
     uint32_t kinds;              // bit k set: the rig has tiles of kind k
     uint32_t jt2;                // k_skin2: joints per palette slot = longest joint list among its tiles (<= 21)
+    uint32_t interleave2;        // k_skin2: XCD x takes tiles x, x + tile_chunks, ... instead of a contiguous chunk
     uint32_t look2;              // k_skin2: palette LDS-DMA runs this many instances ahead (1 or 2); ring = look2 + 1 slots
 };
 

@@ -119,11 +119,28 @@ struct GlobalPal {
 // Scalar v_fma_f32 on purpose (the file is built with -fno-slp-vectorize).  Measured twice: v_pk_fma_f32 with the
 // weight broadcast by op_sel (no {w, w} pair) needs aligned register pairs for rows and sums — 74 -> 95 VGPRs (K=1),
 // 85 -> 119 (K=2) — and the skin stage got slower: C3 4.68 -> 4.76 ms, C5 10.7 -> 11.5 ms (exact: 12.3 -> 13.5).
-template <bool EXACT, int K, class Pal>
-__device__ __forceinline__ void blend_position(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
+// Influences a wave has to visit: weight sets beyond the first are mostly zero on real meshes (JOINTS_1 / WEIGHTS_1
+// exist for a few regions), and a trailing influence whose weight is zero in all 64 lanes adds w * M = 0 to every
+// sum (a sign of zero aside, palette entries being finite), so the wave stops at its last non-zero one: no LDS reads,
+// no arithmetic for the rest.  Wave-uniform (SGPR) and fixed for the block's life.  The first set is always visited.
+// Instantiated (SKIP) only for rigs where it pays — RigDev::skip_sets, decided by the rig compiler: the branch per set
+// keeps the compiler from interleaving the sets' LDS reads and arithmetic, which costs 1-3 % where nothing can be
+// skipped (measured on C5, whose synthetic weights are non-zero up to the eighth in every wave).
+template <int K>
+__device__ __forceinline__ uint32_t wave_influences(const float (&w)[4 * K]) {
+    uint32_t n = 4;
+#pragma unroll
+    for (int a = 4; a < 4 * K; ++a)
+        if (__ballot(w[a] != 0.0f) != 0ull) n = (a | 3) + 1;  // whole sets: one branch per set keeps each set's schedule intact
+    return n;
+}
+
+template <bool EXACT, int K, bool SKIP, class Pal>
+__device__ __forceinline__ void blend_position(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K], uint32_t ninf,
                                                float (&S)[12]) {  // rows of the blended 3x4
 #pragma unroll
     for (int a = 0; a < 4 * K; ++a) {
+        if (SKIP && a >= 4 && (a & 3) == 0 && (uint32_t)a >= ninf) break;  // wave-uniform, tested once per weight set
         const f4* e = pal.entry(li[a]);
         const f4 r0 = e[0], r1 = e[1], r2 = e[2];
         const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
@@ -144,11 +161,12 @@ __device__ __forceinline__ void apply_position(const float (&S)[12], const float
     }
 }
 
-template <bool EXACT, int K, class Pal>
-__device__ __forceinline__ void blend_normal(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
+template <bool EXACT, int K, bool SKIP, class Pal>
+__device__ __forceinline__ void blend_normal(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K], uint32_t ninf,
                                              float (&Nm)[9]) {  // rows of the blended normal matrix
 #pragma unroll
     for (int a = 0; a < 4 * K; ++a) {
+        if (SKIP && a >= 4 && (a & 3) == 0 && (uint32_t)a >= ninf) break;  // wave-uniform, tested once per weight set
         const f4* e = pal.entry(li[a]);
         const f4 n0 = e[3], n1 = e[4], n2 = e[5];  // full 16-byte rows: ds_read_b128, not the slower b96
         const float q[9] = {n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, n2.x, n2.y, n2.z};
@@ -281,8 +299,8 @@ struct Outputs {
 };
 
 // One (instance, vertex): skin from (p, n, t), store, feed the bounds.
-template <bool EXACT, int K, class Pal>
-__device__ __forceinline__ void skin_store(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K],
+template <bool EXACT, int K, bool SKIP, class Pal>
+__device__ __forceinline__ void skin_store(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K], uint32_t ninf,
                                            const float (&p)[3], const float (&n)[3], const float (&t)[3],
                                            bool normalize, bool valid, const Outputs& out, size_t obase, uint32_t olb, float (&op)[3]) {
     // obase (instance offset) is wave-uniform and olb (vertex byte offset) fits 32 bits: the three
@@ -291,13 +309,13 @@ __device__ __forceinline__ void skin_store(const Pal pal, const float (&w)[4 * K
     float on[3], ot[3];
     {
         float S[12];
-        blend_position<EXACT, K>(pal, w, li, S);
+        blend_position<EXACT, K, SKIP>(pal, w, li, ninf, S);
         apply_position<EXACT>(S, p, op);
     }
     if (valid) store3(out.pos + obase, olb, op);
     {
         float Nm[9];
-        blend_normal<EXACT, K>(pal, w, li, Nm);
+        blend_normal<EXACT, K, SKIP>(pal, w, li, ninf, Nm);
         apply_normal<EXACT>(Nm, n, t, normalize, on, ot);
     }
     if (valid) {
@@ -540,6 +558,8 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
 #pragma unroll
         for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
     }
+    constexpr bool SKIP = false;  // (the fallback kernel visits every influence)
+    const uint32_t ninf = 4u * K;
     const Outputs out{cr.pos, cr.nrm, cr.tan};
     const uint32_t olb = v * 12;  // byte offset of this lane's vertex inside an instance's output
     const bool normalize = plan.normalize != 0;
@@ -577,8 +597,8 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
             STAMP(0);
             float op[3];
             auto skin = [&](const float (&p)[3], const float (&n)[3], const float (&t)[3]) {
-                if constexpr (LDSPAL) skin_store<EXACT, K>(LdsPal{pal_s + buf * pal_buf + (size_t)b * JTP * 6}, w, li, p, n, t, normalize, valid, out, obase, olb, op);
-                else skin_store<EXACT, K>(GlobalPal{pal_g + (size_t)i * rig.J * 6}, w, li, p, n, t, normalize, valid, out, obase, olb, op);
+                if constexpr (LDSPAL) skin_store<EXACT, K, SKIP>(LdsPal{pal_s + buf * pal_buf + (size_t)b * JTP * 6}, w, li, ninf, p, n, t, normalize, valid, out, obase, olb, op);
+                else skin_store<EXACT, K, SKIP>(GlobalPal{pal_g + (size_t)i * rig.J * 6}, w, li, ninf, p, n, t, normalize, valid, out, obase, olb, op);
             };
             // Morph data reaches this wave through LDS-DMA requested one instance ahead, so the wait
             // below is "all but my 3 newest vector-memory ops" = the previous instance's stores may
@@ -837,7 +857,7 @@ __global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdD
 constexpr uint32_t kFixChunk = 8;
 constexpr uint32_t kFixLdsBytes = 2 * 128 * 16 + 4 * 6 * 4 + 32 + 64 * sizeof(MorphPair);  // of the block's dynamic LDS
 // fb = this block's index among the kernel's `fix_blocks` blocks (a multiple of 8 * ceil(T / 8))
-template <bool EXACT, int K>
+template <bool EXACT, int K, bool SKIP>
 __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, float4* smem, uint32_t fb, uint32_t fix_blocks) {
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
@@ -872,6 +892,7 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
 #pragma unroll
         for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
     }
+    const uint32_t ninf = SKIP ? wave_influences<K>(w) : 4u * K;
     const uint32_t jstart = rig.tile_joint_start[tile];
     const uint32_t npieces = (rig.tile_joint_start[tile + 1] - jstart) * 6;  // <= 126 for k_skin2's tiles
     const uint32_t joff = tid < npieces ? rig.tile_joints[jstart + tid / 6] * 6 + tid % 6 : 0u;
@@ -933,7 +954,7 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
             }
             lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
             float op[3];
-            skin_store<EXACT, K>(LdsPal{ps}, w, li, p, n, t, normalize, valid && !(SKINRT_FIX_ABLATE & 2), out, (size_t)inst * rig.V * 3,
+            skin_store<EXACT, K, SKIP>(LdsPal{ps}, w, li, ninf, p, n, t, normalize, valid && !(SKINRT_FIX_ABLATE & 2), out, (size_t)inst * rig.V * 3,
                                  (tile * TV + tid) * 12, op);
             if (plan.aabb) {
                 float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
@@ -989,7 +1010,7 @@ __device__ __forceinline__ float wave_bounds_packed(const float (&v)[3], bool up
 
 constexpr uint32_t kSkin2Threads = 256;
 
-template <bool EXACT, int K, int LOOK>
+template <bool EXACT, int K, int LOOK, bool SKIP>
 __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
     constexpr uint32_t TV = kTileVerts;
@@ -999,7 +1020,11 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t xcd = blockIdx.x & 7, kblk = blockIdx.x >> 3;
     const uint32_t tc = xcd % plan.tile_chunks, rc = xcd / plan.tile_chunks;
-    const uint32_t tile = tc * plan.tiles_per_chunk + kblk % plan.tiles_per_chunk;
+    // an XCD's tiles: every tile_chunks-th tile (work per tile varies along the mesh — morph activity, empty weight
+    // sets — and interleaving evens it out over the XCDs: C3 -1.9 %), or one contiguous run where an instance range's
+    // palette is too large for one L2 and neighbouring tiles sharing joints matters more (C5: +1 % interleaved)
+    const uint32_t tile = plan.interleave2 ? (kblk % plan.tiles_per_chunk) * plan.tile_chunks + tc
+                                           : tc * plan.tiles_per_chunk + kblk % plan.tiles_per_chunk;
     const uint32_t rng = rc * plan.ranges_per_chunk2 + kblk / plan.tiles_per_chunk;
     if (tile >= rig.T || rng >= plan.ranges2) return;
     if (rig.tile_lds[tile] != 2) return;  // other tiles: k_skin
@@ -1148,6 +1173,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
 #pragma unroll
         for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
     }
+    const uint32_t ninf = SKIP ? wave_influences<K>(w) : 4u * K;
     // palette pieces this lane moves: piece c = (list position c / 6, 16-byte quarter c % 6), c = lane and lane + 64
     const uint32_t npieces = jcnt * 6;  // <= 126
     uint32_t joff0 = 0, joff1 = 0;      // byte offsets inside one instance's palette
@@ -1247,7 +1273,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         float op[3];
         {
             float S[12];
-            blend_position<EXACT, K>(LdsPal{reinterpret_cast<const f4*>(pal_ring + slot_cur * pal_slot_f)}, w, li, S);
+            blend_position<EXACT, K, SKIP>(LdsPal{reinterpret_cast<const f4*>(pal_ring + slot_cur * pal_slot_f)}, w, li, ninf, S);
             apply_position<EXACT>(S, p, op);
         }
         if (valid) store3(out.pos + obase, olb, op);
@@ -1265,7 +1291,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         float on[3], ot[3];
         {
             float Nm[9];
-            blend_normal<EXACT, K>(LdsPal{reinterpret_cast<const f4*>(pal_ring + slot_cur * pal_slot_f)}, w, li, Nm);
+            blend_normal<EXACT, K, SKIP>(LdsPal{reinterpret_cast<const f4*>(pal_ring + slot_cur * pal_slot_f)}, w, li, ninf, Nm);
             apply_normal<EXACT>(Nm, n, t, normalize, on, ot);
         }
         if (valid) {
@@ -1303,10 +1329,10 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
 // The fix role's kernel.  (Tried: the role inside the k_skin2 launch, its block groups dealt out between the
 // self-staging groups.  Slower — 5.7-6.0 ms against 4.7 on C3: a launch has ONE LDS size, so every fix block takes
 // one of the CU's five 31 KiB block slots from k_skin2; as a kernel of its own it fits into what k_skin2 leaves free.)
-template <bool EXACT, int K>
+template <bool EXACT, int K, bool SKIP>
 __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
-    fix_role<EXACT, K>(rig, cr, plan, smem, blockIdx.x, gridDim.x);
+    fix_role<EXACT, K, SKIP>(rig, cr, plan, smem, blockIdx.x, gridDim.x);
 }
 
 // a14: bounds of one instance = min/max over its tiles' partial bounds (order-independent, exact).
@@ -1393,13 +1419,11 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
             // enough lanes that the longest list is a few chunks per block; blocks past a list's end leave at once
             const uint32_t lanes = std::min((cr.I + kFixChunk - 1) / kFixChunk, std::max(1u, conc.fix_blocks / rig.T));
             const dim3 fgrid(8u * ((rig.T + 7) / 8) * lanes), fblock(256);
-            if (rig.K == 1) {
-                if (plan.exact) hipLaunchKernelGGL((k_skin_fix<true, 1>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan);
-                else hipLaunchKernelGGL((k_skin_fix<false, 1>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan);
-            } else {
-                if (plan.exact) hipLaunchKernelGGL((k_skin_fix<true, 2>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan);
-                else hipLaunchKernelGGL((k_skin_fix<false, 2>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan);
-            }
+#define SKINRT_LAUNCHF(EX, KK, SK) hipLaunchKernelGGL((k_skin_fix<EX, KK, SK>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan)
+            if (rig.K == 1) { if (plan.exact) SKINRT_LAUNCHF(true, 1, false); else SKINRT_LAUNCHF(false, 1, false); }
+            else if (rig.skip_sets) { if (plan.exact) SKINRT_LAUNCHF(true, 2, true); else SKINRT_LAUNCHF(false, 2, true); }
+            else { if (plan.exact) SKINRT_LAUNCHF(true, 2, false); else SKINRT_LAUNCHF(false, 2, false); }
+#undef SKINRT_LAUNCHF
             if ((fe = hipGetLastError()) != hipSuccess) return fe;
             if (side) return hipEventRecord(conc.join, conc.side);
             return hipSuccess;
@@ -1407,14 +1431,16 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         const bool want_fix = cr.fix && !(SKINRT_ABLATE & 32);
         if (want_fix && !conc.skin2_first && (e = launch_fix()) != hipSuccess) return e;
         const dim3 grid(8u * plan.tiles_per_chunk * plan.ranges_per_chunk2), block(kSkin2Threads);
-#define SKINRT_LAUNCH2(EX, KK, LL) hipLaunchKernelGGL((k_skin2<EX, KK, LL>), grid, block, plan.lds_bytes2, s, rig, cr, plan)
-        if (plan.look2 == 1) {
-            if (rig.K == 1) { if (plan.exact) SKINRT_LAUNCH2(true, 1, 1); else SKINRT_LAUNCH2(false, 1, 1); }
-            else { if (plan.exact) SKINRT_LAUNCH2(true, 2, 1); else SKINRT_LAUNCH2(false, 2, 1); }
-        } else {
-            if (rig.K == 1) { if (plan.exact) SKINRT_LAUNCH2(true, 1, 2); else SKINRT_LAUNCH2(false, 1, 2); }
-            else { if (plan.exact) SKINRT_LAUNCH2(true, 2, 2); else SKINRT_LAUNCH2(false, 2, 2); }
-        }
+#define SKINRT_LAUNCH2(EX, KK, LL, SK) hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK>), grid, block, plan.lds_bytes2, s, rig, cr, plan)
+#define SKINRT_LAUNCH2K(EX, LL)                                                            \
+    do {                                                                                   \
+        if (rig.K == 1) SKINRT_LAUNCH2(EX, 1, LL, false);                                  \
+        else if (rig.skip_sets) SKINRT_LAUNCH2(EX, 2, LL, true);                           \
+        else SKINRT_LAUNCH2(EX, 2, LL, false);                                             \
+    } while (0)
+        if (plan.look2 == 1) { if (plan.exact) SKINRT_LAUNCH2K(true, 1); else SKINRT_LAUNCH2K(false, 1); }
+        else { if (plan.exact) SKINRT_LAUNCH2K(true, 2); else SKINRT_LAUNCH2K(false, 2); }
+#undef SKINRT_LAUNCH2K
 #undef SKINRT_LAUNCH2
         e = hipGetLastError();
         if (e == hipSuccess && want_fix && conc.skin2_first) e = launch_fix();

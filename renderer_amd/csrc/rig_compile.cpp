@@ -288,6 +288,22 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
             for (uint32_t a = 0; a < W; ++a) { wt[a * TV + l] = wt[a * TV]; li[a * TV + l] = li[a * TV]; }
         }
     }
+    // Waves (64 consecutive lanes of a tile) whose weight sets beyond the first are zero in every lane can stop after
+    // the sets they use (wave_influences in kernels_skin.hip); the kernels that test for it are chosen when at least an
+    // eighth of the (wave, extra set) units of a two-set rig would be skipped.
+    r.skippable_set_waves = r.extra_set_waves = 0;
+    if (K >= 2)
+        for (uint32_t t = 0; t < T; ++t)
+            for (uint32_t wv = 0; wv < TV / 64; ++wv) {
+                uint32_t last = 0;  // last set with a non-zero weight in this wave
+                const float* wt = &r.wts[(size_t)t * W * TV + wv * 64];
+                for (uint32_t a = 4; a < W; ++a)
+                    for (uint32_t l = 0; l < 64; ++l)
+                        if (wt[a * TV + l] != 0.0f) { last = a / 4; break; }
+                r.extra_set_waves += K - 1;
+                r.skippable_set_waves += K - 1 - last;
+            }
+    r.skip_sets = K == 2 && r.skippable_set_waves * 8 >= r.extra_set_waves && r.skippable_set_waves > 0;
     if (V) {
         r.joints0.assign(d->joints[0], d->joints[0] + (size_t)V * 4);
         r.weights0.assign(d->weights[0], d->weights[0] + (size_t)V * 4);
@@ -402,6 +418,7 @@ void fill_rig_info(const CompiledRig& r, uint64_t device_bytes, skinrt_rig_info*
     info->exact_arithmetic = r.exact;
     info->bind_extent = r.bind_extent;
     info->weight_channel_clips = r.weight_channel_clips;
+    info->skip_weight_sets = r.skip_sets ? 1u : 0u;
 }
 
 }  // namespace skinrt

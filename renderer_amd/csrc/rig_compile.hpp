@@ -86,6 +86,9 @@ struct CompiledRig {
     uint32_t max_tile_joints_any = 0;
     uint32_t max_tile_joints2 = 0;           // over the self-staging kernel's tiles (kind 2): <= 21
     uint32_t lds_tiles = 0;
+    uint64_t extra_set_waves = 0;            // (wave, weight set beyond the first) units of the tiled mesh
+    uint64_t skippable_set_waves = 0;        // those whose weights are zero in all 64 lanes, trailing
+    bool skip_sets = false;                  // the skin kernels that stop a wave after its last used set are worth it
     // morph: (tile, target) pairs, targets ascending inside a tile
     std::vector<uint32_t> tile_pair_start;  // [T+1]
     std::vector<MorphPair> pairs;

@@ -212,6 +212,36 @@ def test_stages_run_separately_give_the_same_frame(oracle32):
         c.close(); r.close()
 
 
+@pytest.mark.parametrize("skin_path", [0, 1])
+@pytest.mark.parametrize("shape,exact", [("c5", 1), ("c3", 1), ("c3", 2)])   # (FMA on the C5-shaped chain: see test_c5_shape_reduced)
+def test_waves_stop_at_their_last_nonzero_influence(oracle32, shape, exact, skin_path):
+    """Two weight sets, the second one empty over most of the mesh (as on real meshes): a wave whose 64 vertices have
+    zero weights from some influence on stops there (wave_influences in kernels_skin.hip).  The oracle visits all
+    eight; the results must not differ.  Vertex ranges are chosen so that waves end at 4, 5, 6, 7 and 8 influences,
+    including a wave where a single lane keeps the wave at 8."""
+    if shape == "c5":
+        spec = synth.scaled(synth.CONFIGS["c5"], verts=2100, joints=96, nodes=100, targets=6, keys=4)
+    else:
+        spec = synth.scaled(synth.CONFIGS["c3"], verts=2100, sets=2, targets=6, keys=4)
+    rig = synth.make_rig(spec)
+    assert len(rig.weights) == 2
+    w1 = rig.weights[1]
+    w1[:] = np.abs(w1) + 0.01         # every influence of the second set non-zero to start with
+    w1[0:256] = 0.0                   # a whole tile stops at 4
+    w1[256:320, 1:] = 0.0             # wave stops at 5
+    w1[320:384, 2:] = 0.0             # 6
+    w1[384:448, 3:] = 0.0             # 7
+    w1[448:512] = 0.0
+    w1[500, 3] = 0.25                 # one lane keeps its wave at 8 (influences 4-6 of that wave are all zero)
+    w1[1024:2100] = 0.0               # the ragged last tile too
+    crowd = synth.make_crowd(spec, rig, instances=90)
+    got = run_gpu(rig, crowd, exact_arithmetic=exact, skin_path=skin_path)
+    assert got["info"].skip_weight_sets == 1      # the rig compiler chose the kernels that test for it
+    ref = run_oracle(oracle32, rig, crowd)
+    _check_all(got, ref, exact_skin=exact == 1, tag="influences:")
+    assert api.validate_rig(synth.make_rig(spec)).skip_weight_sets == 0   # the unmodified rig: nothing to skip
+
+
 def test_crowd_reused_over_frames(oracle32):
     """One crowd, several frames with different clocks, clips and morph weights: every frame must equal the oracle
     run on that frame's inputs alone — nothing of the previous frame (work lists and their counts, active-target
