@@ -175,10 +175,15 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
         if (p.lds_bytes2 > 64 * 1024) p.v2 = 0;
         uint64_t r2 = ((uint64_t)I * std::max<uint32_t>(1, r.T) + want_blocks - 1) / want_blocks;
         p.range2 = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(r2, 1), kSkin2Range);
+        if (const char* ev = getenv("SKINRT_RANGE2")) p.range2 = std::min<uint32_t>(kSkin2Range, std::max(1, atoi(ev)));  // experiments
         p.ranges2 = I ? (I + p.range2 - 1) / p.range2 : 0;
         p.ranges_per_chunk2 = (std::max<uint32_t>(1, p.ranges2) + rcs - 1) / rcs;
-        p.interleave2 = (uint64_t)p.range2 * r.J * 96 <= (2u << 20) ? 1 : 0;  // a block range's palettes fit an XCD's L2 twice over
-        if (const char* ev = getenv("SKINRT_TILE_INTERLEAVE")) p.interleave2 = atoi(ev) ? 1 : 0;
+        // a block range's palettes fit an XCD's L2 twice over: interleave fully; else runs of 16 tiles (4096 vertices), which
+        // keep most of the joint sharing between neighbouring tiles (C5: as fast as one contiguous chunk) and still spread
+        // a mesh's busy regions over the XCDs
+        p.run2 = (uint64_t)p.range2 * r.J * 96 <= (2u << 20) ? 1 : std::min<uint32_t>(16, p.tiles_per_chunk);
+        if (const char* ev = getenv("SKINRT_TILE_RUN")) p.run2 = std::min<uint32_t>(p.tiles_per_chunk, std::max(1, atoi(ev)));
+        p.tiles_per_chunk2 = (p.tiles_per_chunk + p.run2 - 1) / p.run2 * p.run2;
     }
     p.exact = r.exact;  // skinrt_config.exact_arithmetic resolved per rig at compile time
     p.normalize = cfg.normalize_outputs ? 1 : 0;

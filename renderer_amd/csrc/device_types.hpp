@@ -90,7 +90,9 @@ struct SkinPlan {
     uint32_t lds_bytes2;         // dynamic LDS per k_skin2 block
     uint32_t kinds;              // bit k set: the rig has tiles of kind k
     uint32_t jt2;                // k_skin2: joints per palette slot = longest joint list among its tiles (<= 21)
-    uint32_t interleave2;        // k_skin2: XCD x takes tiles x, x + tile_chunks, ... instead of a contiguous chunk
+    uint32_t run2;               // k_skin2: an XCD's tiles come in runs of run2 consecutive tiles, the runs dealt round-robin over
+                                 // the tile chunks (1: fully interleaved; tiles_per_chunk2: one contiguous chunk per XCD)
+    uint32_t tiles_per_chunk2;   // tiles_per_chunk rounded up to whole runs
     uint32_t look2;              // k_skin2: palette LDS-DMA runs this many instances ahead (1 or 2); ring = look2 + 1 slots
 };
 

@@ -1023,9 +1023,10 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
     // an XCD's tiles: every tile_chunks-th tile (work per tile varies along the mesh — morph activity, empty weight
     // sets — and interleaving evens it out over the XCDs: C3 -1.9 %), or one contiguous run where an instance range's
     // palette is too large for one L2 and neighbouring tiles sharing joints matters more (C5: +1 % interleaved)
-    const uint32_t tile = plan.interleave2 ? (kblk % plan.tiles_per_chunk) * plan.tile_chunks + tc
-                                           : tc * plan.tiles_per_chunk + kblk % plan.tiles_per_chunk;
-    const uint32_t rng = rc * plan.ranges_per_chunk2 + kblk / plan.tiles_per_chunk;
+    // (plan.run2 = tiles per run: 1 = fully interleaved, tiles_per_chunk2 = one contiguous chunk per XCD)
+    const uint32_t jt = kblk % plan.tiles_per_chunk2;
+    const uint32_t tile = ((jt / plan.run2) * plan.tile_chunks + tc) * plan.run2 + jt % plan.run2;
+    const uint32_t rng = rc * plan.ranges_per_chunk2 + kblk / plan.tiles_per_chunk2;
     if (tile >= rig.T || rng >= plan.ranges2) return;
     if (rig.tile_lds[tile] != 2) return;  // other tiles: k_skin
     const uint32_t i0 = rng * plan.range2;
@@ -1385,7 +1386,8 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         return hipErrorInvalidValue;
     if (plan.v2 && (plan.range2 == 0 || plan.range2 > kSkin2Range || (uint64_t)plan.ranges2 * plan.range2 < cr.I ||
                     plan.lds_bytes2 > 64 * 1024 || rig.K > 2 || plan.jt2 == 0 || plan.jt2 > 21 || plan.look2 < 1 || plan.look2 > 2 ||
-                    (uint64_t)plan.ranges_per_chunk2 * (8 / plan.tile_chunks) < plan.ranges2))
+                    (uint64_t)plan.ranges_per_chunk2 * (8 / plan.tile_chunks) < plan.ranges2 ||
+                    plan.run2 == 0 || plan.tiles_per_chunk2 % plan.run2 != 0 || plan.tiles_per_chunk2 < plan.tiles_per_chunk))
         return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     // tiles of kind 2 (short joint lists): the self-staging kernel unless it is switched off
@@ -1430,7 +1432,7 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         };
         const bool want_fix = cr.fix && !(SKINRT_ABLATE & 32);
         if (want_fix && !conc.skin2_first && (e = launch_fix()) != hipSuccess) return e;
-        const dim3 grid(8u * plan.tiles_per_chunk * plan.ranges_per_chunk2), block(kSkin2Threads);
+        const dim3 grid(8u * plan.tiles_per_chunk2 * plan.ranges_per_chunk2), block(kSkin2Threads);
 #define SKINRT_LAUNCH2(EX, KK, LL, SK) hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK>), grid, block, plan.lds_bytes2, s, rig, cr, plan)
 #define SKINRT_LAUNCH2K(EX, LL)                                                            \
     do {                                                                                   \
