@@ -1,4 +1,4 @@
-//! Raw bindings of `include/skinrt.h` (ABI version 3), field for field and function for function.
+//! Raw bindings of `include/skinrt.h` (ABI version 4), field for field and function for function.
 //!
 //! `tests/test_rust_bindings.py` (CPU) parses the `#[repr(C)]` structs and the `extern "C"` block below, lays
 //! the structs out by the C rules and compares sizes, field offsets and the function list with what `gcc`
@@ -14,7 +14,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const SKINRT_ABI_VERSION: c_int = 3;
+pub const SKINRT_ABI_VERSION: c_int = 4;
 
 pub const SKINRT_OK: c_int = 0;
 pub const SKINRT_E_INVALID: c_int = -1;
@@ -54,6 +54,10 @@ pub struct skinrt_rig {
 }
 #[repr(C)]
 pub struct skinrt_crowd {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct skinrt_node {
     _private: [u8; 0],
 }
 
@@ -208,4 +212,17 @@ extern "C" {
                                     index_count: u32, out: *mut f32, out_device_ms: *mut f32) -> c_int;
     pub fn skinrt_calculate_tangent_noalloc(ctx: *mut skinrt_ctx, mode: u32, dev_positions: *const f32, vertex_count: u32,
                                             dev_indices: *const u32, index_count: u32, dev_out: *mut f32) -> c_int;
+
+    pub fn skinrt_node_create(config: *const skinrt_config, devices: *const i32, device_count: u32, desc: *const skinrt_rig_desc,
+                              instances: u32, out_node: *mut *mut skinrt_node) -> c_int;
+    pub fn skinrt_node_destroy(node: *mut skinrt_node) -> c_int;
+    pub fn skinrt_node_shard_count(node: *mut skinrt_node, out_count: *mut u32) -> c_int;
+    pub fn skinrt_node_get_shard(node: *mut skinrt_node, shard: u32, out_ctx: *mut *mut skinrt_ctx, out_crowd: *mut *mut skinrt_crowd,
+                                 out_first: *mut u32, out_count: *mut u32) -> c_int;
+    pub fn skinrt_node_set_clocks(node: *mut skinrt_node, tau: *const f32, clip_id: *const u32) -> c_int;
+    pub fn skinrt_node_set_morph_weights(node: *mut skinrt_node, weights: *const f32) -> c_int;
+    pub fn skinrt_node_set_root_transforms(node: *mut skinrt_node, matrices: *const f32) -> c_int;
+    pub fn skinrt_node_evaluate(node: *mut skinrt_node, stages_mask: u32) -> c_int;
+    pub fn skinrt_node_synchronize(node: *mut skinrt_node) -> c_int;
+    pub fn skinrt_node_download_aabbs(node: *mut skinrt_node, host_out: *mut f32) -> c_int;
 }

@@ -198,3 +198,76 @@ impl Drop for Crowd<'_> {
         unsafe { sys::skinrt_destroy_crowd(self.raw) };
     }
 }
+
+/// One crowd sharded over several devices of this process (`skinrt_node_*`): instance `i` lives on the shard
+/// `skinrt_shard_range` assigns it to; there is no exchange step on the data path, `evaluate` enqueues on every device
+/// and returns, `synchronize` waits for all of them.  Inputs are whole-crowd slices; outputs are reached per shard.
+pub struct Node {
+    raw: *mut sys::skinrt_node,
+    instances: u32,
+    targets: u32,
+}
+
+/// A shard's handles, borrowed from its [`Node`]: pass them to the per-device entry points of `skinrt-sys`.
+pub struct Shard {
+    pub ctx: *mut sys::skinrt_ctx,
+    /// null for an empty shard (more devices than instances)
+    pub crowd: *mut sys::skinrt_crowd,
+    pub first: u32,
+    pub count: u32,
+}
+
+impl Node {
+    pub fn new(mut config: sys::skinrt_config, devices: &[i32], flat: &flatten::FlatRig, instances: u32) -> Result<Self, Error> {
+        config.struct_size = std::mem::size_of::<sys::skinrt_config>() as u32;
+        let d = flatten::RigDesc::new(flat);
+        let mut raw = ptr::null_mut();
+        check(unsafe { sys::skinrt_node_create(&config, devices.as_ptr(), devices.len() as u32, &d.desc, instances, &mut raw) })?;
+        Ok(Self { raw, instances, targets: d.desc.target_count })
+    }
+    pub fn shards(&self) -> Result<Vec<Shard>, Error> {
+        let mut n = 0u32;
+        check(unsafe { sys::skinrt_node_shard_count(self.raw, &mut n) })?;
+        (0..n).map(|g| {
+            let mut s = Shard { ctx: ptr::null_mut(), crowd: ptr::null_mut(), first: 0, count: 0 };
+            check(unsafe { sys::skinrt_node_get_shard(self.raw, g, &mut s.ctx, &mut s.crowd, &mut s.first, &mut s.count) })?;
+            Ok(s)
+        }).collect()
+    }
+    pub fn set_clocks(&mut self, tau: &[f32], clip_id: Option<&[u32]>) -> Result<(), Error> {
+        if tau.len() != self.instances as usize || clip_id.map(|c| c.len() != tau.len()).unwrap_or(false) {
+            return Err(Error::new(sys::SKINRT_E_INVALID, "one clock (and clip) per instance"));
+        }
+        check(unsafe { sys::skinrt_node_set_clocks(self.raw, tau.as_ptr(), clip_id.map_or(ptr::null(), |c| c.as_ptr())) })
+    }
+    pub fn set_morph_weights(&mut self, weights: Option<&[f32]>) -> Result<(), Error> {
+        if weights.map(|w| w.len() != self.instances as usize * self.targets as usize).unwrap_or(false) {
+            return Err(Error::new(sys::SKINRT_E_INVALID, "target_count weights per instance"));
+        }
+        check(unsafe { sys::skinrt_node_set_morph_weights(self.raw, weights.map_or(ptr::null(), |w| w.as_ptr())) })
+    }
+    pub fn set_root_transforms(&mut self, matrices: Option<&[[f32; 16]]>) -> Result<(), Error> {
+        if matrices.map(|m| m.len() != self.instances as usize).unwrap_or(false) {
+            return Err(Error::new(sys::SKINRT_E_INVALID, "one root matrix per instance"));
+        }
+        check(unsafe { sys::skinrt_node_set_root_transforms(self.raw, matrices.map_or(ptr::null(), |m| m.as_ptr().cast())) })
+    }
+    pub fn evaluate(&mut self, stages: u32) -> Result<(), Error> {
+        check(unsafe { sys::skinrt_node_evaluate(self.raw, stages) })
+    }
+    pub fn synchronize(&self) -> Result<(), Error> {
+        check(unsafe { sys::skinrt_node_synchronize(self.raw) })
+    }
+    /// Every instance's bounds `[min xyz, max xyz]`, gathered from all shards in instance order.
+    pub fn aabbs(&self) -> Result<Vec<[f32; 6]>, Error> {
+        let mut out = vec![[0.0f32; 6]; self.instances as usize];
+        check(unsafe { sys::skinrt_node_download_aabbs(self.raw, out.as_mut_ptr().cast()) })?;
+        Ok(out)
+    }
+}
+
+impl Drop for Node {
+    fn drop(&mut self) {
+        unsafe { sys::skinrt_node_destroy(self.raw) };
+    }
+}

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SKINRT_ABI_VERSION 3
+#define SKINRT_ABI_VERSION 4
 #define SKINRT_API __attribute__((visibility("default")))
 
 /* ---- error codes ---------------------------------------------------------------- */
@@ -365,6 +365,37 @@ SKINRT_API int skinrt_calculate_tangent(skinrt_ctx* ctx, uint32_t mode, const fl
 #define SKINRT_TANGENT_NOALLOC_MAX_INDICES 1572864u
 SKINRT_API int skinrt_calculate_tangent_noalloc(skinrt_ctx* ctx, uint32_t mode, const float* dev_positions, uint32_t vertex_count,
                                      const uint32_t* dev_indices, uint32_t index_count, float* dev_out);
+
+/* ---- one crowd over several GPUs of this process ------------------------------------
+ * No reference counterpart (the reference renders on one adapter).  A node holds one ctx, one copy of the rig and
+ * one crowd per listed device; instance i lives on the shard skinrt_shard_range assigns it to, at row i - first.
+ * There is no exchange step on the data path.  All calls come from one host thread: skinrt_node_evaluate enqueues
+ * the stages on every device's stream in turn and returns, so the devices run side by side;
+ * skinrt_node_synchronize waits for all of them.  A device may be listed more than once (its shards then share
+ * it).  Error behaviour as the single-device calls': the first failing shard's code, skinrt_last_error names it. */
+typedef struct skinrt_node skinrt_node;
+
+/* config->device is ignored (devices[] takes its place).  Fails as a whole — nothing is left allocated — when any
+ * shard's skinrt_init / skinrt_upload_rig / skinrt_create_crowd fails. */
+SKINRT_API int skinrt_node_create(const skinrt_config* config, const int32_t* devices, uint32_t device_count,
+                                  const skinrt_rig_desc* desc, uint32_t instances, skinrt_node** out_node);
+SKINRT_API int skinrt_node_destroy(skinrt_node* node);
+SKINRT_API int skinrt_node_shard_count(skinrt_node* node, uint32_t* out_count);
+/* The shard's handles, for every per-device call above (skinrt_get_positions, the exporters, skinrt_last_stage_ms,
+ * skinrt_get_stream ...).  *out_crowd is NULL for an empty shard (more devices than instances).  Any out pointer
+ * may be NULL.  The handles belong to the node. */
+SKINRT_API int skinrt_node_get_shard(skinrt_node* node, uint32_t shard, skinrt_ctx** out_ctx, skinrt_crowd** out_crowd,
+                                     uint32_t* out_first, uint32_t* out_count);
+/* Whole-crowd host arrays, [instances] / [instances][target_count] / [instances][16]: each shard is handed its rows
+ * (skinrt_set_clocks, skinrt_set_morph_weights, skinrt_set_root_transforms; NULL means what it means there). */
+SKINRT_API int skinrt_node_set_clocks(skinrt_node* node, const float* tau, const uint32_t* clip_id);
+SKINRT_API int skinrt_node_set_morph_weights(skinrt_node* node, const float* weights);
+SKINRT_API int skinrt_node_set_root_transforms(skinrt_node* node, const float* matrices);
+SKINRT_API int skinrt_node_evaluate(skinrt_node* node, uint32_t stages_mask);
+SKINRT_API int skinrt_node_synchronize(skinrt_node* node);
+/* The per-frame gather a renderer needs for culling: every shard's per-instance bounds into host_out[instances][6]
+ * (min xyz, max xyz), in instance order.  Waits for the shards' streams. */
+SKINRT_API int skinrt_node_download_aabbs(skinrt_node* node, float* host_out);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,9 @@ EXPORTS = [
     "skinrt_export_skin_uniform", "skinrt_export_interleaved", "skinrt_calculate_tangent",
     "skinrt_calculate_tangent_noalloc", "skinrt_export_skin_uniform_device", "skinrt_export_interleaved_device",
     "skinrt_shard_range",
+    "skinrt_node_create", "skinrt_node_destroy", "skinrt_node_shard_count", "skinrt_node_get_shard", "skinrt_node_set_clocks",
+    "skinrt_node_set_morph_weights", "skinrt_node_set_root_transforms", "skinrt_node_evaluate", "skinrt_node_synchronize",
+    "skinrt_node_download_aabbs",
 ]
 
 
@@ -85,6 +88,16 @@ def load_library() -> C.CDLL:
         "skinrt_shard_range": [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
         "skinrt_calculate_tangent": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(C.c_float)],
         "skinrt_calculate_tangent_noalloc": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp],
+        "skinrt_node_create": [C.POINTER(Config), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(RigDesc), C.c_uint32, C.POINTER(vp)],
+        "skinrt_node_destroy": [vp],
+        "skinrt_node_shard_count": [vp, C.POINTER(C.c_uint32)],
+        "skinrt_node_get_shard": [vp, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
+        "skinrt_node_set_clocks": [vp, vp, vp],
+        "skinrt_node_set_morph_weights": [vp, vp],
+        "skinrt_node_set_root_transforms": [vp, vp],
+        "skinrt_node_evaluate": [vp, C.c_uint32],
+        "skinrt_node_synchronize": [vp],
+        "skinrt_node_download_aabbs": [vp, vp],
     }
     for g in ("positions", "normals", "tangents", "aabbs", "palette", "world", "keyframe_index"):
         sigs[f"skinrt_get_{g}"] = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
@@ -332,3 +345,87 @@ class Crowd:
         if self.handle:
             self.ctx.lib.skinrt_destroy_crowd(self.handle)
             self.handle = C.c_void_p()
+
+
+class Node:
+    """One crowd sharded over several devices of this process (skinrt_node_*): whole-crowd inputs in, per-shard
+    outputs through `shard(g)`, which lends a Crowd view of the shard's handles (owned by the node)."""
+
+    def __init__(self, devices, data: RigData, instances: int, **cfg):
+        self.lib = load_library()
+        self.data, self.instances = data, int(instances)
+        self.config = make_config(device=0, **cfg)
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        desc = data.to_desc()
+        self.handle = C.c_void_p()
+        _check(self.lib.skinrt_node_create(C.byref(self.config), devs, len(devices), C.byref(desc), self.instances, C.byref(self.handle)))
+
+    @property
+    def shard_count(self) -> int:
+        n = C.c_uint32()
+        _check(self.lib.skinrt_node_shard_count(self.handle, C.byref(n)))
+        return int(n.value)
+
+    def shard(self, g: int):
+        """(crowd view or None for an empty shard, first instance, count)."""
+        ctx_h, crowd_h, first, count = C.c_void_p(), C.c_void_p(), C.c_uint32(), C.c_uint32()
+        _check(self.lib.skinrt_node_get_shard(self.handle, g, C.byref(ctx_h), C.byref(crowd_h), C.byref(first), C.byref(count)))
+        if not crowd_h.value:
+            return None, int(first.value), int(count.value)
+        ctx = Context.__new__(Context)
+        ctx.lib, ctx.config, ctx.handle = self.lib, self.config, ctx_h
+        rig = Rig.__new__(Rig)
+        rig.ctx, rig.data, rig.handle = ctx, self.data, C.c_void_p()
+        crowd = Crowd.__new__(Crowd)
+        crowd.ctx, crowd.rig, crowd.instances, crowd.handle = ctx, rig, int(count.value), crowd_h
+        return crowd, int(first.value), int(count.value)
+
+    def set_clocks(self, tau, clip_id=None):
+        tau = np.ascontiguousarray(tau, dtype=np.float32)
+        assert tau.shape == (self.instances,)
+        cp = None
+        if clip_id is not None:
+            clip_id = np.ascontiguousarray(clip_id, dtype=np.uint32)
+            assert clip_id.shape == (self.instances,)
+            cp = clip_id.ctypes.data_as(C.c_void_p)
+        _check(self.lib.skinrt_node_set_clocks(self.handle, tau.ctypes.data_as(C.c_void_p), cp))
+
+    def set_morph_weights(self, weights):
+        wp = None
+        if weights is not None:
+            weights = np.ascontiguousarray(weights, dtype=np.float32)
+            assert weights.shape == (self.instances, self.data.target_count)
+            wp = weights.ctypes.data_as(C.c_void_p)
+        _check(self.lib.skinrt_node_set_morph_weights(self.handle, wp))
+
+    def set_root_transforms(self, matrices):
+        mp = None
+        if matrices is not None:
+            matrices = np.ascontiguousarray(matrices, dtype=np.float32)
+            assert matrices.shape == (self.instances, 16)
+            mp = matrices.ctypes.data_as(C.c_void_p)
+        _check(self.lib.skinrt_node_set_root_transforms(self.handle, mp))
+
+    def evaluate(self, stages: int = abi.STAGE_ALL, sync: bool = False):
+        _check(self.lib.skinrt_node_evaluate(self.handle, stages))
+        if sync:
+            self.synchronize()
+
+    def synchronize(self):
+        _check(self.lib.skinrt_node_synchronize(self.handle))
+
+    def aabbs(self) -> np.ndarray:
+        out = np.empty((self.instances, 2, 3), np.float32)
+        _check(self.lib.skinrt_node_download_aabbs(self.handle, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if self.handle:
+            self.lib.skinrt_node_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -726,4 +726,135 @@ int skinrt_calculate_tangent_noalloc(skinrt_ctx* ctx, uint32_t mode, const float
     return SKINRT_OK;
 }
 
+// ---- one crowd over several devices of this process (VERDICT r1 "multi-GPU behind the C ABI") ----------
+// A node is nothing but one (ctx, rig, crowd) per listed device and the sharding rule of skinrt_shard_range: there is
+// no exchange step on the data path, every entry point above is asynchronous on its ctx's stream, so one host thread
+// keeps all devices busy — evaluate enqueues on each shard in turn and returns.  The setters take whole-crowd host
+// arrays and hand each shard its rows.
+struct skinrt_node {
+    struct Shard {
+        skinrt_ctx* ctx = nullptr;
+        skinrt_rig* rig = nullptr;
+        skinrt_crowd* crowd = nullptr;  // nullptr: the shard is empty (more devices than instances)
+        uint32_t first = 0, count = 0;
+    };
+    std::vector<Shard> shards;
+    uint32_t instances = 0, M = 0;
+};
+
+int skinrt_node_destroy(skinrt_node* node) {
+    if (!node) return SKINRT_OK;
+    int rc = SKINRT_OK;
+    for (auto& sh : node->shards) {
+        if (sh.crowd) { const int r = skinrt_destroy_crowd(sh.crowd); if (rc == SKINRT_OK) rc = r; }
+        if (sh.rig) { const int r = skinrt_destroy_rig(sh.rig); if (rc == SKINRT_OK) rc = r; }
+        if (sh.ctx) { const int r = skinrt_destroy_ctx(sh.ctx); if (rc == SKINRT_OK) rc = r; }
+    }
+    delete node;
+    return rc;
+}
+
+int skinrt_node_create(const skinrt_config* config, const int32_t* devices, uint32_t device_count, const skinrt_rig_desc* desc,
+                       uint32_t instances, skinrt_node** out_node) {
+    if (!config || !devices || !desc || !out_node) return fail(SKINRT_E_INVALID, "skinrt_node_create: NULL argument");
+    if (config->struct_size != sizeof(skinrt_config)) return fail(SKINRT_E_INVALID, "skinrt_config.struct_size mismatch");
+    if (device_count == 0 || device_count > 64) return fail(SKINRT_E_INVALID, "skinrt_node_create: device_count must be 1..64");
+    *out_node = nullptr;
+    skinrt_node* node = new (std::nothrow) skinrt_node;
+    if (!node) return fail(SKINRT_E_NOMEM, "out of host memory");
+    node->instances = instances;
+    node->M = desc->target_count;
+    try { node->shards.resize(device_count); } catch (const std::bad_alloc&) { delete node; return fail(SKINRT_E_NOMEM, "out of host memory"); }
+    for (uint32_t g = 0; g < device_count; ++g) {
+        skinrt_node::Shard& sh = node->shards[g];
+        skinrt_config cfg = *config;
+        cfg.device = devices[g];  // the same device may be listed more than once: its shards then share it
+        int rc = skinrt_shard_range(instances, g, device_count, &sh.first, &sh.count);
+        if (rc == SKINRT_OK) rc = skinrt_init(&cfg, &sh.ctx);
+        if (rc == SKINRT_OK) rc = skinrt_upload_rig(sh.ctx, desc, &sh.rig);
+        if (rc == SKINRT_OK && sh.count) rc = skinrt_create_crowd(sh.ctx, sh.rig, sh.count, &sh.crowd);
+        if (rc != SKINRT_OK) {
+            const std::string why = g_err;  // destroy calls below may overwrite it
+            (void)skinrt_node_destroy(node);
+            return fail(rc, "skinrt_node_create, shard " + std::to_string(g) + ": " + why);
+        }
+    }
+    *out_node = node;
+    return SKINRT_OK;
+}
+
+int skinrt_node_shard_count(skinrt_node* node, uint32_t* out_count) {
+    if (!node || !out_count) return fail(SKINRT_E_INVALID, "skinrt_node_shard_count: NULL argument");
+    *out_count = (uint32_t)node->shards.size();
+    return SKINRT_OK;
+}
+
+int skinrt_node_get_shard(skinrt_node* node, uint32_t shard, skinrt_ctx** out_ctx, skinrt_crowd** out_crowd, uint32_t* out_first,
+                          uint32_t* out_count) {
+    if (!node) return fail(SKINRT_E_INVALID, "node is NULL");
+    if (shard >= node->shards.size()) return fail(SKINRT_E_RANGE, "shard index out of range");
+    const skinrt_node::Shard& sh = node->shards[shard];
+    if (out_ctx) *out_ctx = sh.ctx;
+    if (out_crowd) *out_crowd = sh.crowd;
+    if (out_first) *out_first = sh.first;
+    if (out_count) *out_count = sh.count;
+    return SKINRT_OK;
+}
+
+int skinrt_node_set_clocks(skinrt_node* node, const float* tau, const uint32_t* clip_id) {
+    if (!node) return fail(SKINRT_E_INVALID, "node is NULL");
+    if (!tau) return fail(SKINRT_E_INVALID, "tau is NULL");
+    for (auto& sh : node->shards)
+        if (sh.crowd)
+            if (int rc = skinrt_set_clocks(sh.crowd, tau + sh.first, clip_id ? clip_id + sh.first : nullptr)) return rc;
+    return SKINRT_OK;
+}
+
+int skinrt_node_set_morph_weights(skinrt_node* node, const float* weights) {
+    if (!node) return fail(SKINRT_E_INVALID, "node is NULL");
+    for (auto& sh : node->shards)
+        if (sh.crowd)
+            if (int rc = skinrt_set_morph_weights(sh.crowd, weights ? weights + (size_t)sh.first * node->M : nullptr)) return rc;
+    return SKINRT_OK;
+}
+
+int skinrt_node_set_root_transforms(skinrt_node* node, const float* matrices) {
+    if (!node) return fail(SKINRT_E_INVALID, "node is NULL");
+    for (auto& sh : node->shards)
+        if (sh.crowd)
+            if (int rc = skinrt_set_root_transforms(sh.crowd, matrices ? matrices + (size_t)sh.first * 16 : nullptr)) return rc;
+    return SKINRT_OK;
+}
+
+int skinrt_node_evaluate(skinrt_node* node, uint32_t stages_mask) {
+    if (!node) return fail(SKINRT_E_INVALID, "node is NULL");
+    for (auto& sh : node->shards)
+        if (sh.crowd)
+            if (int rc = skinrt_evaluate(sh.crowd, stages_mask)) return rc;  // enqueues and returns: the devices run side by side
+    return SKINRT_OK;
+}
+
+int skinrt_node_synchronize(skinrt_node* node) {
+    if (!node) return fail(SKINRT_E_INVALID, "node is NULL");
+    int rc = SKINRT_OK;
+    for (auto& sh : node->shards) {  // wait for every device even after a failure
+        const int r = skinrt_synchronize(sh.ctx);
+        if (rc == SKINRT_OK) rc = r;
+    }
+    return rc;
+}
+
+int skinrt_node_download_aabbs(skinrt_node* node, float* host_out) {
+    if (!node || !host_out) return fail(SKINRT_E_INVALID, "skinrt_node_download_aabbs: NULL argument");
+    for (auto& sh : node->shards) {
+        if (!sh.crowd) continue;
+        float* dev = nullptr;
+        uint64_t n = 0;
+        if (int rc = skinrt_get_aabbs(sh.crowd, &dev, &n)) return rc;
+        if (int rc = skinrt_download(sh.ctx, dev, host_out + (size_t)sh.first * 6, n * 4)) return rc;
+    }
+    return SKINRT_OK;
+}
+
 }  // extern "C"
+

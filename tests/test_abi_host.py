@@ -250,3 +250,25 @@ def test_init_without_gpu_fails_loudly():
     with pytest.raises(api.SkinrtError) as e:
         api.Context()
     assert e.value.code == abi.E_DEVICE
+
+
+def test_node_entry_points_reject_bad_arguments_without_a_device():
+    """skinrt_node_*: argument errors come back as codes before any device is touched."""
+    lib = api.load_library()
+    rig = synth.make_rig(synth.tiny_spec())
+    desc = rig.to_desc()
+    cfg = api.make_config()
+    node = C.c_void_p()
+    devs = (C.c_int32 * 2)(0, 1)
+    assert lib.skinrt_node_create(None, devs, 2, C.byref(desc), 4, C.byref(node)) == abi.E_INVALID
+    assert lib.skinrt_node_create(C.byref(cfg), None, 2, C.byref(desc), 4, C.byref(node)) == abi.E_INVALID
+    assert lib.skinrt_node_create(C.byref(cfg), devs, 0, C.byref(desc), 4, C.byref(node)) == abi.E_INVALID
+    assert lib.skinrt_node_create(C.byref(cfg), devs, 65, C.byref(desc), 4, C.byref(node)) == abi.E_INVALID
+    assert lib.skinrt_node_create(C.byref(cfg), devs, 2, C.byref(desc), 4, None) == abi.E_INVALID
+    for fn in ("skinrt_node_set_clocks", "skinrt_node_set_morph_weights", "skinrt_node_set_root_transforms"):
+        assert getattr(lib, fn)(None, None, None) == abi.E_INVALID if fn.endswith("clocks") else getattr(lib, fn)(None, None) == abi.E_INVALID
+    assert lib.skinrt_node_evaluate(None, abi.STAGE_ALL) == abi.E_INVALID
+    assert lib.skinrt_node_synchronize(None) == abi.E_INVALID
+    assert lib.skinrt_node_download_aabbs(None, None) == abi.E_INVALID
+    assert lib.skinrt_node_shard_count(None, None) == abi.E_INVALID
+    assert lib.skinrt_node_destroy(None) == abi.OK
