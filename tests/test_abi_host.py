@@ -272,3 +272,10 @@ def test_node_entry_points_reject_bad_arguments_without_a_device():
     assert lib.skinrt_node_download_aabbs(None, None) == abi.E_INVALID
     assert lib.skinrt_node_shard_count(None, None) == abi.E_INVALID
     assert lib.skinrt_node_destroy(None) == abi.OK
+
+
+def test_graft_entry_build_checks_the_headers_version():
+    """build() is the driver's "does it build" step: it must compare the library with the header, not with a literal
+    (a stale literal failed the step for a whole round without any test noticing)."""
+    src = open(os.path.join(os.path.dirname(HEADER), "..", "__graft_entry__.py")).read()
+    assert "SKINRT_ABI_VERSION" in src and not re.search(r"skinrt_abi_version\(\)\s*==\s*\d", src)
