@@ -344,6 +344,136 @@ __global__ __launch_bounds__(64) void k_propagate_quad(const RigDev rig, const C
     }
 }
 
+// ---- the same chain with the locals prefetched through an LDS ring ------------------------------------------------
+// k_propagate_quad needs ~10 dependent instructions per node, yet took 264 ns per node (C5: 1.08 ms for the 4096-node
+// chain, with the GPU nearly empty — 16 lanes per instance is about one wave per CU): it waited for memory.  The next
+// chunk's local columns were requested one chunk of arithmetic (~0.3 us) ahead and come from HBM, the parents' scalar
+// loads were waited for in every chunk, and deepening the register prefetch does not survive the compiler (a ring of
+// register arrays carried round the loop is copied at the back-edge, with a wait for every load in flight).
+// Here a second wave does nothing but fetch: block = 2 waves x 4 instances.  The LOADER wave moves whole chunks —
+// kPropChunk nodes x 4 instances x 48 B, contiguous per node in local_t[n][i][12], plus the chunk's parents — from
+// global memory straight into an LDS ring with LDS-DMA (no registers, nothing for a compiler to copy), kPropDepth
+// chunks ahead; its vmcnt counts nothing but those transfers, so "chunk j+1 has landed" is one counted wait.  The
+// CHAIN wave reads its column and the parents from LDS and writes the world matrices; it never waits for memory.  One
+// LDS-only barrier per chunk hands a slot over.  Element order is k_propagate_quad's: bit-equal.
+constexpr int kRingChunk = 16;                             // nodes per chunk: 16 x 12 16-byte pieces = 3 DMA instructions
+constexpr int kRingDepth = 8;                              // chunks in flight
+constexpr int kRingSlots = kRingDepth + 1;
+constexpr int kRingSlotBytes = kRingChunk * 192 + 64;      // locals + parents
+
+__device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(128) void k_propagate_ring(const RigDev rig, const CrowdDev cr, const float* __restrict__ local_t) {
+    __shared__ __align__(16) char ring[kRingSlots * kRingSlotBytes];
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t N = rig.N, I = cr.I, i0 = blockIdx.x * 4;
+    const uint32_t nchunks = (N + kRingChunk - 1) / kRingChunk;
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+
+    if (wave == 1) {
+        // ================= loader wave =================
+        // piece p = k * 64 + lane (k = 0..2) of a chunk: node p / 12, then (instance, row) = p % 12
+        auto issue = [&](uint32_t j) {
+            const uint32_t c0 = min(j, nchunks - 1) * kRingChunk;  // past the end: the last chunk again, into a slot nobody reads
+            const float* gbase = local_t + (size_t)c0 * I * 12;     // wave-uniform
+            const uint32_t slot = ring_base + (j % kRingSlots) * kRingSlotBytes;
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) {
+                const uint32_t pc = k * 64 + lane, nd = min(pc / 12, N - 1 - c0), q = pc % 12;
+                const uint32_t inst = min(i0 + q / 3, I - 1);  // a block's idle instances shadow the last real one
+                const uint32_t voff = (nd * I + inst) * 48 + (q % 3) * 16;
+                const uint32_t ldsb = slot + k * 1024;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(gbase), "s"(ldsb) : "memory");
+            }
+            {
+                const int32_t* pbase = rig.parent + c0;
+                const uint32_t voff = min(lane, N - 1 - c0) * 4;
+                const uint32_t ldsb = slot + kRingChunk * 192;
+                if (lane < 16) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(pbase), "s"(ldsb) : "memory");
+            }
+        };
+        for (uint32_t j = 0; j < (uint32_t)kRingDepth; ++j) issue(j);
+        for (uint32_t j = 0; j <= nchunks; ++j) {
+            // every chunk is exactly 4 transfers: all but the newest kRingDepth - 1 chunks have landed
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (kRingDepth - 1)) : "memory");
+            ring_barrier();  // chunk j is the chain wave's; the slot of chunk j - 1 is free again
+            if (j < nchunks) issue(j + kRingDepth);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be writing LDS when the block ends
+        return;
+    }
+
+    // ================= chain wave =================
+    const uint32_t e = lane & 15, q = lane >> 4;
+    const uint32_t i = i0 + q;
+    const bool act = i < I && e < 12;
+    const uint32_t r = e >> 2, c = e & 3;
+    float* w = cr.world + (size_t)min(i, I - 1) * N * 12;
+    const bool has_root = cr.root != nullptr;
+    float root_e = has_root ? cr.root[(size_t)min(i, I - 1) * 12 + min(e, 11u)] : 0.0f;
+    // waited for HERE, once: left pending, the compiler answers every later read of root_e — one per node — with
+    // s_waitcnt vmcnt(0), and in the loop that means waiting for the previous node's store
+    asm volatile("" : "+v"(root_e));
+    float prev = 0.0f;  // this lane's element of the previous node's world matrix
+    for (uint32_t j = 0; j < nchunks; ++j) {
+        ring_barrier();  // chunk j has landed
+        const char* slot = ring + (j % kRingSlots) * kRingSlotBytes;
+        const float* loc = reinterpret_cast<const float*>(slot) + q * 12 + c;  // + node * 48 floats: column c of my instance's local
+        const int32_t* par = reinterpret_cast<const int32_t*>(slot + kRingChunk * 192);
+        // the whole chunk's LDS reads are issued before the chain starts (a ragged last chunk reads the clamped
+        // duplicates the loader put there), so their latency is paid once per chunk, not once per node
+        float L0[kRingChunk], L1[kRingChunk], L2[kRingChunk];
+        int32_t P[kRingChunk];
+#pragma unroll
+        for (int d = 0; d < kRingChunk; ++d) { L0[d] = loc[d * 48]; L1[d] = loc[d * 48 + 4]; L2[d] = loc[d * 48 + 8]; P[d] = par[d]; }
+        // A whole chunk of plain chain links (parent = the node before, the common case in a deep rig) needs no per-node
+        // tests: with one wave per SIMD every instruction costs its full issue latency, and the tests, selects and
+        // per-store EXEC masks were two thirds of the instructions per node.  Lane d checks node d's parent.
+        const uint32_t c0 = j * kRingChunk;
+        const bool link = lane >= (uint32_t)kRingChunk || par[lane] == (int32_t)(c0 + lane) - 1;
+        if (c0 + kRingChunk <= N && c0 > 0 && __ballot(!link) == 0ull) {  // wave-uniform
+            if (act) {  // one EXEC mask for the chunk; quads 0-2 of a live instance are complete, which is all DPP needs
+                float* wn = w + (size_t)c0 * 12 + e;
+#pragma unroll
+                for (int d = 0; d < kRingChunk; ++d) {
+                    const float ax = quad_bcast<0x00>(prev), ay = quad_bcast<0x55>(prev), az = quad_bcast<0xAA>(prev), aw = quad_bcast<0xFF>(prev);
+                    float out = (ax * L0[d] + ay * L1[d]) + az * L2[d];
+                    if (c == 3) out = out + aw;
+                    wn[d * 12] = out;
+                    prev = out;
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int d = 0; d < kRingChunk; ++d) {
+            const uint32_t n = c0 + d;
+            if (n < N) {  // wave-uniform
+                const float l0 = L0[d], l1 = L1[d], l2 = L2[d];
+                const int32_t p = __builtin_amdgcn_readfirstlane(P[d]);
+                float pe = prev;
+                bool mul = true;
+                if (p < 0) {
+                    pe = root_e;
+                    mul = has_root;
+                } else if (p != (int32_t)n - 1) {
+                    pe = w[(size_t)p * 12 + min(e, 11u)];  // written earlier by this same lane (rare: chains are the common case)
+                    // consumed HERE, so that the wait for this load stays inside the branch: placed at the join it would
+                    // make every node wait for the previous node's store
+                    asm volatile("" : "+v"(pe));
+                }
+                const float ax = quad_bcast<0x00>(pe), ay = quad_bcast<0x55>(pe), az = quad_bcast<0xAA>(pe), aw = quad_bcast<0xFF>(pe);
+                float out = (ax * l0 + ay * l1) + az * l2;
+                if (c == 3) out = out + aw;
+                if (!mul) out = r == 0 ? l0 : (r == 1 ? l1 : l2);  // root without a root transform: world = local
+                if (act) w[(size_t)n * 12 + e] = out;
+                prev = out;
+            }
+        }
+    }
+    ring_barrier();  // the loader's last one
+}
+
 __global__ __launch_bounds__(256) void k_palette(const RigDev rig, const CrowdDev cr) {
     const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= (uint64_t)cr.I * rig.J) return;
@@ -437,7 +567,9 @@ hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t quirk, Po
     }
     const uint64_t in = (uint64_t)cr.I * rig.N;
     if (!local_t) hipLaunchKernelGGL(k_sample_local, dim3((uint32_t)((in + 255) / 256)), dim3(256), 0, s, rig, cr, quirk);
-    hipLaunchKernelGGL(k_propagate_quad, dim3((cr.I + 3) / 4), dim3(64), 0, s, rig, cr, local_t);
+    // (the ring kernel addresses a chunk of 16 nodes with 32-bit byte offsets)
+    if (local_t && (uint64_t)kRingChunk * cr.I * 48 < 0xffffffffull) hipLaunchKernelGGL(k_propagate_ring, dim3((cr.I + 3) / 4), dim3(128), 0, s, rig, cr, local_t);
+    else hipLaunchKernelGGL(k_propagate_quad, dim3((cr.I + 3) / 4), dim3(64), 0, s, rig, cr, local_t);
     if (rig.J) {
         const uint64_t ij = (uint64_t)cr.I * rig.J;
         hipLaunchKernelGGL(k_palette, dim3((uint32_t)((ij + 255) / 256)), dim3(256), 0, s, rig, cr);
