@@ -49,6 +49,11 @@ for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursiv
     if cur: spans.append(cur[1] - cur[0])
     if spans:
         print(f"  skin stage span per frame (first start -> last end of k_classify / k_skin2 / k_skin_fix): avg {sum(spans)/len(spans)/1e6:.3f} ms, min {min(spans)/1e6:.3f}, max {max(spans)/1e6:.3f} over {len(spans)} frames")
+        timed = int(os.environ.get("PROF_TIMED", "0"))  # bench.py's --steps: the frames its own timers cover
+        if 0 < timed < len(spans):
+            t = spans[-timed:]
+            print(f"  ... of which the last {timed} (bench.py's timed steps, after its warm-up): avg {sum(t)/len(t)/1e6:.3f} ms, min {min(t)/1e6:.3f}, max {max(t)/1e6:.3f}")
+        print("  spans, ms: " + " ".join(f"{x/1e6:.2f}" for x in spans))
 for p in sorted(glob.glob(os.path.join(d, "pmc*"))):
     if not os.path.isdir(p): continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))

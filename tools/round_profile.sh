@@ -4,6 +4,8 @@
 # usage: tools/round_profile.sh <tag> [bench args...]     e.g. tools/round_profile.sh r01_c3 --steps 5 --warmup 2
 set -u
 TAG=$1; shift
+# bench.py's --steps, so that the summary can set the timed frames apart from the warm-up
+prev=""; for a in "$@"; do [ "$prev" = "--steps" ] && export PROF_TIMED=$a; prev=$a; done
 tools/prof.sh $TAG "$@" || exit 1
 python3 tools/prof_summary.py gpurun_out/$TAG > gpurun_out/$TAG/summary.txt || exit 1
 python3 tools/make_traffic.py gpurun_out/$TAG "$@" > gpurun_out/$TAG/traffic.json || exit 1
