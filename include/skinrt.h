@@ -297,7 +297,11 @@ SKINRT_API int skinrt_get_aabbs(skinrt_crowd* crowd, float** out_dev, uint64_t* 
 /* Joint palette [I][J][24] f32: 3 rows x 4 of the joint matrix (row r = m[r][0..3] incl.
  * translation), then 3 rows x 4 of the normal matrix (4th of each row = 0).
  * Same numbers as SkinMatrix (uniform/skin.rs:12-17), transposed to rows; see
- * skinrt_export_skin_uniform for the reference byte layout. */
+ * skinrt_export_skin_uniform for the reference byte layout.
+ * Sign of zero: the values compare equal (==) to glam's, but a zero in the normal rows may carry the other sign.
+ * glam inverts the full 4x4 (uniform/skin.rs:33), whose cofactor sums include "+ 0 * x" terms that turn a -0.0 into
+ * +0.0; the kernels invert the affine 3x4 and have no such terms.  (Seen on rigs whose rest rotations are all
+ * identity.)  Nothing downstream of a zero normal-matrix entry depends on its sign except another zero's sign. */
 SKINRT_API int skinrt_get_palette(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
 /* Node world matrices [I][N][12] f32, 3 rows x 4 (the Mat4's first three rows). */
 SKINRT_API int skinrt_get_world(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
