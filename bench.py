@@ -159,6 +159,12 @@ def main():
     launched = "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         spawn_ranks(args.gpus, sys.argv[1:])  # never returns
+    # stdout carries ONE JSON line and nothing else.  Libraries write there behind Python's back (RCCL prints its
+    # version block and its warnings to fd 1, at init and again at the first collective), so fd 1 is pointed at stderr
+    # for the whole run and the line goes to a private copy of the original stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -316,7 +322,7 @@ def main():
             one, many = cpu_baseline(rig_data, spec)
             out["cpu_baseline"] = one
             out["cpu_baseline_mt"] = many
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
 
     crowd.close(); rig.close(); ctx.close()
     if launched:
