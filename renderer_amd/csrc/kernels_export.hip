@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_export_interleaved(const ExportSrc src,
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const uint32_t d = tid + 256u * r;
-            if (d < nv * 3) rec[(d / 3) * S + field[a] + d % 3] = __float_as_uint(arrays[a][d]);
+            if (d < nv * 3) rec[(d / 3) * S + field[a] + d % 3] = __float_as_uint(__builtin_nontemporal_load(arrays[a] + d));
         }
 #pragma unroll
     for (uint32_t r = 0; r < NA; ++r) {
@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void k_export_interleaved(const ExportSrc src,
     const uint32_t nd = nv * S;
     uint32_t* out = dst + out0;
     if ((out0 & 3u) == 0) {
-        for (uint32_t d = tid * 4; d + 4 <= nd; d += 1024) *reinterpret_cast<uint4*>(out + d) = *reinterpret_cast<const uint4*>(rec + d);
+        // streaming stores: the records are written once and read by somebody else's kernels
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        for (uint32_t d = tid * 4; d + 4 <= nd; d += 1024) __builtin_nontemporal_store(*reinterpret_cast<const u4*>(rec + d), reinterpret_cast<u4*>(out + d));
         if (tid < (nd & 3u)) out[(nd & ~3u) + tid] = rec[(nd & ~3u) + tid];
     } else {
         for (uint32_t d = tid; d < nd; d += 256) out[d] = rec[d];
