@@ -92,10 +92,11 @@ typedef struct skinrt_config {
      *    bit-equal to the fp32 CPU restatement (oracle/).  2: FMA in the same association — within
      *    1e-5 rel / 1e-6 abs of it on well-conditioned rigs, about 10 % faster.  0 (default): chosen per rig
      *    at upload: FMA unless a joint's inverse bind translation exceeds 4 units in some component —
-     *    there the skinning sums cancel, fused and unfused rounding differ by more than the 1e-6
-     *    absolute bar (BASELINE config 5: a 4096-joint chain 400 units long), and the exact kernels are
-     *    used.  skinrt_rig_info.exact_arithmetic reports the choice.  Pose stages are always
-     *    contraction-free. */
+     *    there the position sums cancel, fused and unfused rounding differ by more than the 1e-6
+     *    absolute bar (BASELINE config 5: a 4096-joint chain 400 units long), and positions are computed
+     *    contraction-free (bit-equal); normals and tangents, whose 3x3 sums carry no translation and do
+     *    not cancel, stay fused and inside the bar.  skinrt_rig_info.exact_arithmetic reports the
+     *    choice.  Pose stages are always contraction-free. */
     uint32_t exact_arithmetic;
     /* 0: choose per rig; 1: wavefront-per-instance pose kernel; 2: split pose kernels
      *    (sample / lane-per-instance propagate / palette) used for very deep or large rigs. */
@@ -202,7 +203,7 @@ typedef struct skinrt_rig_info {
     uint32_t max_channels;         /* Cmax */
     uint64_t morph_entries;        /* nonzero (vertex,target) pairs kept after compaction */
     uint64_t device_bytes;         /* bytes of device memory the rig occupies */
-    uint32_t exact_arithmetic;     /* 1: the skin stage runs contraction-free on this rig (skinrt_config.exact_arithmetic) */
+    uint32_t exact_arithmetic;     /* skin stage on this rig: 0 fused, 1 contraction-free, 2 positions contraction-free and normals / tangents fused (skinrt_config.exact_arithmetic) */
     float bind_extent;             /* largest |translation component| over the inverse bind matrices */
     uint32_t weight_channel_clips; /* clips that carry a SKINRT_PATH_WEIGHTS channel */
     /* 1: enough 64-vertex waves of the mesh have all-zero weights in the second weight set that the skin stage runs

@@ -226,7 +226,12 @@ class Crowd:
     @property
     def exact(self) -> bool:
         """True when the skin stage runs contraction-free on this crowd's rig (bit-equal to the fp32 oracle)."""
-        return bool(self.rig.info.exact_arithmetic)
+        return self.rig.info.exact_arithmetic == 1
+
+    @property
+    def exact_positions(self) -> bool:
+        """positions carry the fp32 oracle's bits (exact_arithmetic 1, or 2: normals / tangents fused)"""
+        return self.rig.info.exact_arithmetic != 0
 
     @property
     def placement(self) -> dict:

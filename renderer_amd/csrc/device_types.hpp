@@ -78,7 +78,7 @@ struct SkinPlan {
     uint32_t pair_gshift; // log2 of the lane-group size the loader uses to compact one instance's pairs
     uint32_t max_pairs; // largest number of (tile, target) morph pairs in one tile
     uint32_t lds_bytes; // dynamic LDS per block
-    uint32_t exact;     // 1: contraction-free arithmetic (bit-equal to the fp32 oracle)
+    uint32_t exact;     // 0: FMA, 1: contraction-free arithmetic (bit-equal to the fp32 oracle), 2: positions contraction-free, normals / tangents FMA
     uint32_t normalize; // shader.wgsl:217-218 variant
     uint32_t aabb;      // write per-(instance,tile) bounds
     uint32_t debug;     // unused

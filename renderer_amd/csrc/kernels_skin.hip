@@ -38,6 +38,11 @@ __device__ unsigned long long g_stamps[16];
 #ifndef SKINRT_ABLATE
 #define SKINRT_ABLATE 0
 #endif
+// Timing experiments (results wrong): 2 = influence 0 takes its rows from registers (no LDS read), 4 = normal rows as 2 x b128 + b32,
+// 8 = wave w of a block visits only (w + 1) * K influences (what sorting a tile's vertices by influence count would buy)
+#ifndef SKINRT_EXP
+#define SKINRT_EXP 0
+#endif
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -141,8 +146,11 @@ __device__ __forceinline__ void blend_position(const Pal pal, const float (&w)[4
 #pragma unroll
     for (int a = 0; a < 4 * K; ++a) {
         if (SKIP && a >= 4 && (a & 3) == 0 && (uint32_t)a >= ninf) break;  // wave-uniform, tested once per weight set
+        if (((SKINRT_EXP & 8) && a > 0 && (uint32_t)a >= ninf) || ((SKINRT_EXP & 16) && a > 0)) break;
         const f4* e = pal.entry(li[a]);
-        const f4 r0 = e[0], r1 = e[1], r2 = e[2];
+        f4 r0, r1, r2;
+        if ((SKINRT_EXP & 2) && a == 0) { r0 = f4{w[0], w[1], w[2], w[3]}; r1 = r0 * 2.0f; r2 = r0 * 3.0f; }
+        else { r0 = e[0]; r1 = e[1]; r2 = e[2]; }
         const float m[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
 #pragma unroll
         for (int x = 0; x < 12; ++x) S[x] = a == 0 ? mul_nc(w[0], m[x]) : madd<EXACT>(w[a], m[x], S[x]);
@@ -167,10 +175,14 @@ __device__ __forceinline__ void blend_normal(const Pal pal, const float (&w)[4 *
 #pragma unroll
     for (int a = 0; a < 4 * K; ++a) {
         if (SKIP && a >= 4 && (a & 3) == 0 && (uint32_t)a >= ninf) break;  // wave-uniform, tested once per weight set
+        if (((SKINRT_EXP & 8) && a > 0 && (uint32_t)a >= ninf) || ((SKINRT_EXP & 16) && a > 0)) break;
         const f4* e = pal.entry(li[a]);
-        const f4 n0 = e[3], n1 = e[4], n2 = e[5];  // full 16-byte rows: ds_read_b128, not the slower b96
+        f4 n0, n1, n2;
+        if ((SKINRT_EXP & 2) && a == 0) { n0 = f4{w[0], w[1], w[2], w[3]}; n1 = n0 * 2.0f; n2 = n0 * 3.0f; }
+        else if (SKINRT_EXP & 4) { n0 = e[3]; n1 = e[4]; n2 = f4{n0.w, n1.w, reinterpret_cast<const float*>(e + 5)[0], 0.0f}; }
+        else { n0 = e[3]; n1 = e[4]; n2 = e[5]; }  // full 16-byte rows: ds_read_b128, not the slower b96
         const float q[9] = {n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, n2.x, n2.y, n2.z};
-        asm volatile("" ::"v"(n0.w), "v"(n1.w), "v"(n2.w));
+        if (!(SKINRT_EXP & 4)) asm volatile("" ::"v"(n0.w), "v"(n1.w), "v"(n2.w));
 #pragma unroll
         for (int x = 0; x < 9; ++x) Nm[x] = a == 0 ? mul_nc(w[0], q[x]) : madd<EXACT>(w[a], q[x], Nm[x]);
         if ((a & 1) && a + 1 < 4 * K) __builtin_amdgcn_sched_barrier(0);
@@ -181,12 +193,13 @@ __device__ __forceinline__ void apply_normal(const float (&Nm)[9], const float (
                                              float (&on)[3], float (&ot)[3]) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
+        constexpr bool EX = EXACT;
         float a = mul_nc(Nm[3 * r], n[0]);
-        a = madd<EXACT>(Nm[3 * r + 1], n[1], a);
-        on[r] = madd<EXACT>(Nm[3 * r + 2], n[2], a);
+        a = madd<EX>(Nm[3 * r + 1], n[1], a);
+        on[r] = madd<EX>(Nm[3 * r + 2], n[2], a);
         float b = mul_nc(Nm[3 * r], t[0]);
-        b = madd<EXACT>(Nm[3 * r + 1], t[1], b);
-        ot[r] = madd<EXACT>(Nm[3 * r + 2], t[2], b);
+        b = madd<EX>(Nm[3 * r + 1], t[1], b);
+        ot[r] = madd<EX>(Nm[3 * r + 2], t[2], b);
     }
     if (normalize) {  // shader.wgsl:217-218 — v / sqrt(dot(v,v))
         const float ln = sqrtf(madd<true>(on[2], on[2], madd<true>(on[1], on[1], mul_nc(on[0], on[0]))));
@@ -299,7 +312,7 @@ struct Outputs {
 };
 
 // One (instance, vertex): skin from (p, n, t), store, feed the bounds.
-template <bool EXACT, int K, bool SKIP, class Pal>
+template <bool EXACT, bool NEXACT, int K, bool SKIP, class Pal>
 __device__ __forceinline__ void skin_store(const Pal pal, const float (&w)[4 * K], const uint32_t (&li)[4 * K], uint32_t ninf,
                                            const float (&p)[3], const float (&n)[3], const float (&t)[3],
                                            bool normalize, bool valid, const Outputs& out, size_t obase, uint32_t olb, float (&op)[3]) {
@@ -315,8 +328,8 @@ __device__ __forceinline__ void skin_store(const Pal pal, const float (&w)[4 * K
     if (valid) store3(out.pos + obase, olb, op);
     {
         float Nm[9];
-        blend_normal<EXACT, K, SKIP>(pal, w, li, ninf, Nm);
-        apply_normal<EXACT>(Nm, n, t, normalize, on, ot);
+        blend_normal<NEXACT, K, SKIP>(pal, w, li, ninf, Nm);
+        apply_normal<NEXACT>(Nm, n, t, normalize, on, ot);
     }
     if (valid) {
         store3(out.nrm + obase, olb, on);
@@ -597,8 +610,8 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
             STAMP(0);
             float op[3];
             auto skin = [&](const float (&p)[3], const float (&n)[3], const float (&t)[3]) {
-                if constexpr (LDSPAL) skin_store<EXACT, K, SKIP>(LdsPal{pal_s + buf * pal_buf + (size_t)b * JTP * 6}, w, li, ninf, p, n, t, normalize, valid, out, obase, olb, op);
-                else skin_store<EXACT, K, SKIP>(GlobalPal{pal_g + (size_t)i * rig.J * 6}, w, li, ninf, p, n, t, normalize, valid, out, obase, olb, op);
+                if constexpr (LDSPAL) skin_store<EXACT, EXACT, K, SKIP>(LdsPal{pal_s + buf * pal_buf + (size_t)b * JTP * 6}, w, li, ninf, p, n, t, normalize, valid, out, obase, olb, op);
+                else skin_store<EXACT, EXACT, K, SKIP>(GlobalPal{pal_g + (size_t)i * rig.J * 6}, w, li, ninf, p, n, t, normalize, valid, out, obase, olb, op);
             };
             // Morph data reaches this wave through LDS-DMA requested one instance ahead, so the wait
             // below is "all but my 3 newest vector-memory ops" = the previous instance's stores may
@@ -857,10 +870,11 @@ __global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdD
 constexpr uint32_t kFixChunk = 8;
 constexpr uint32_t kFixLdsBytes = 2 * 128 * 16 + 4 * 6 * 4 + 32 + 64 * sizeof(MorphPair);  // of the block's dynamic LDS
 // fb = this block's index among the kernel's `fix_blocks` blocks (a multiple of 8 * ceil(T / 8))
-template <bool EXACT, int K, bool SKIP>
+template <int AR, int K, bool SKIP>
 __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, float4* smem, uint32_t fb, uint32_t fix_blocks) {
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
+    constexpr bool EXACT = AR != 0, NEXACT = AR == 1;  // AR 2: positions contraction-free, normals / tangents fused
     f4 (*pal_s)[128] = reinterpret_cast<f4 (*)[128]>(smem);                            // [2][128]
     float (*part)[6] = reinterpret_cast<float (*)[6]>(pal_s + 2);                        // [4][6] (+ 32 B pad)
     MorphPair* pairs_l = reinterpret_cast<MorphPair*>(reinterpret_cast<char*>(part) + 4 * 6 * 4 + 32);  // the tile's first 64 pair records
@@ -954,7 +968,7 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
             }
             lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
             float op[3];
-            skin_store<EXACT, K, SKIP>(LdsPal{ps}, w, li, ninf, p, n, t, normalize, valid && !(SKINRT_FIX_ABLATE & 2), out, (size_t)inst * rig.V * 3,
+            skin_store<EXACT, NEXACT, K, SKIP>(LdsPal{ps}, w, li, ninf, p, n, t, normalize, valid && !(SKINRT_FIX_ABLATE & 2), out, (size_t)inst * rig.V * 3,
                                  (tile * TV + tid) * 12, op);
             if (plan.aabb) {
                 float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
@@ -1010,11 +1024,12 @@ __device__ __forceinline__ float wave_bounds_packed(const float (&v)[3], bool up
 
 constexpr uint32_t kSkin2Threads = 256;
 
-template <bool EXACT, int K, int LOOK, bool SKIP>
+template <int AR, int K, int LOOK, bool SKIP>
 __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
+    constexpr bool EXACT = AR != 0, NEXACT = AR == 1;  // AR 2: positions contraction-free, normals / tangents fused
     constexpr uint32_t L = LOOK, R = L + 1;  // palette lookahead (plan.look2) and ring slots
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1174,7 +1189,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
 #pragma unroll
         for (int a = 0; a < W; ++a) { w[a] = wt[a * TV]; li[a] = lp[a * TV]; }
     }
-    const uint32_t ninf = SKIP ? wave_influences<K>(w) : 4u * K;
+    const uint32_t ninf = (SKINRT_EXP & 8) ? (wave + 1) * K : (SKIP ? wave_influences<K>(w) : 4u * K);
     // palette pieces this lane moves: piece c = (list position c / 6, 16-byte quarter c % 6), c = lane and lane + 64
     const uint32_t npieces = jcnt * 6;  // <= 126
     uint32_t joff0 = 0, joff1 = 0;      // byte offsets inside one instance's palette
@@ -1292,8 +1307,8 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
         float on[3], ot[3];
         {
             float Nm[9];
-            blend_normal<EXACT, K, SKIP>(LdsPal{reinterpret_cast<const f4*>(pal_ring + slot_cur * pal_slot_f)}, w, li, ninf, Nm);
-            apply_normal<EXACT>(Nm, n, t, normalize, on, ot);
+            blend_normal<NEXACT, K, SKIP>(LdsPal{reinterpret_cast<const f4*>(pal_ring + slot_cur * pal_slot_f)}, w, li, ninf, Nm);
+            apply_normal<NEXACT>(Nm, n, t, normalize, on, ot);
         }
         if (valid) {
             store3(out.nrm + obase, olb, on);
@@ -1330,10 +1345,10 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const
 // The fix role's kernel.  (Tried: the role inside the k_skin2 launch, its block groups dealt out between the
 // self-staging groups.  Slower — 5.7-6.0 ms against 4.7 on C3: a launch has ONE LDS size, so every fix block takes
 // one of the CU's five 31 KiB block slots from k_skin2; as a kernel of its own it fits into what k_skin2 leaves free.)
-template <bool EXACT, int K, bool SKIP>
+template <int AR, int K, bool SKIP>
 __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
-    fix_role<EXACT, K, SKIP>(rig, cr, plan, smem, blockIdx.x, gridDim.x);
+    fix_role<AR, K, SKIP>(rig, cr, plan, smem, blockIdx.x, gridDim.x);
 }
 
 // a14: bounds of one instance = min/max over its tiles' partial bounds (order-independent, exact).
@@ -1422,9 +1437,16 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
             const uint32_t lanes = std::min((cr.I + kFixChunk - 1) / kFixChunk, std::max(1u, conc.fix_blocks / rig.T));
             const dim3 fgrid(8u * ((rig.T + 7) / 8) * lanes), fblock(256);
 #define SKINRT_LAUNCHF(EX, KK, SK) hipLaunchKernelGGL((k_skin_fix<EX, KK, SK>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan)
-            if (rig.K == 1) { if (plan.exact) SKINRT_LAUNCHF(true, 1, false); else SKINRT_LAUNCHF(false, 1, false); }
-            else if (rig.skip_sets) { if (plan.exact) SKINRT_LAUNCHF(true, 2, true); else SKINRT_LAUNCHF(false, 2, true); }
-            else { if (plan.exact) SKINRT_LAUNCHF(true, 2, false); else SKINRT_LAUNCHF(false, 2, false); }
+#define SKINRT_LAUNCHFA(KK, SK)                                                            \
+    do {                                                                                   \
+        if (plan.exact == 1) SKINRT_LAUNCHF(1, KK, SK);                                    \
+        else if (plan.exact == 2) SKINRT_LAUNCHF(2, KK, SK);                               \
+        else SKINRT_LAUNCHF(0, KK, SK);                                                    \
+    } while (0)
+            if (rig.K == 1) SKINRT_LAUNCHFA(1, false);
+            else if (rig.skip_sets) SKINRT_LAUNCHFA(2, true);
+            else SKINRT_LAUNCHFA(2, false);
+#undef SKINRT_LAUNCHFA
 #undef SKINRT_LAUNCHF
             if ((fe = hipGetLastError()) != hipSuccess) return fe;
             if (side) return hipEventRecord(conc.join, conc.side);
@@ -1440,8 +1462,8 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         else if (rig.skip_sets) SKINRT_LAUNCH2(EX, 2, LL, true);                           \
         else SKINRT_LAUNCH2(EX, 2, LL, false);                                             \
     } while (0)
-        if (plan.look2 == 1) { if (plan.exact) SKINRT_LAUNCH2K(true, 1); else SKINRT_LAUNCH2K(false, 1); }
-        else { if (plan.exact) SKINRT_LAUNCH2K(true, 2); else SKINRT_LAUNCH2K(false, 2); }
+        if (plan.look2 == 1) { if (plan.exact == 1) SKINRT_LAUNCH2K(1, 1); else if (plan.exact == 2) SKINRT_LAUNCH2K(2, 1); else SKINRT_LAUNCH2K(0, 1); }
+        else { if (plan.exact == 1) SKINRT_LAUNCH2K(1, 2); else if (plan.exact == 2) SKINRT_LAUNCH2K(2, 2); else SKINRT_LAUNCH2K(0, 2); }
 #undef SKINRT_LAUNCH2K
 #undef SKINRT_LAUNCH2
         e = hipGetLastError();

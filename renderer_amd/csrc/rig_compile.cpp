@@ -207,7 +207,9 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
     }
     {
         const uint32_t mode = cfg ? cfg->exact_arithmetic : 0;
-        r.exact = mode == 1 ? 1u : (mode == 2 ? 0u : (r.bind_extent > kExactBindExtent ? 1u : 0u));
+        // chosen per rig (mode 0), a far-from-origin rig gets 2: positions contraction-free (their sums cancel), normals and
+        // tangents fused (3x3 rows of magnitude ~1, no translation: nothing cancels; C5 skin stage -6 %)
+        r.exact = mode == 1 ? 1u : (mode == 2 ? 0u : (r.bind_extent > kExactBindExtent ? 2u : 0u));
     }
 
     // ---- mesh ------------------------------------------------------------------------------
