@@ -39,7 +39,10 @@ __device__ unsigned long long g_stamps[16];
 #define SKINRT_ABLATE 0
 #endif
 // Timing experiments (results wrong): 2 = influence 0 takes its rows from registers (no LDS read), 4 = normal rows as 2 x b128 + b32,
-// 8 = wave w of a block visits only (w + 1) * K influences (what sorting a tile's vertices by influence count would buy)
+// 8 = wave w of a block visits only (w + 1) * K influences (what sorting a tile's vertices by influence count would buy),
+// 16 = one influence per vertex.  (A further switch sent k_skin2's outputs through an LDS transposition and two block
+// barriers per instance, which sorted tiles would need for coalesced stores: +0.9 ms on C5, +0.5 ms on C3 — as much as
+// switch 8 saves; sorted tiles were not built.  tools/ubench/store_perm.hip: scattered 12-byte stores are 7x slower.)
 #ifndef SKINRT_EXP
 #define SKINRT_EXP 0
 #endif
