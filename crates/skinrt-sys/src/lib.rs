@@ -14,7 +14,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const SKINRT_ABI_VERSION: c_int = 4;
+pub const SKINRT_ABI_VERSION: c_int = 5;
 
 pub const SKINRT_OK: c_int = 0;
 pub const SKINRT_E_INVALID: c_int = -1;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SKINRT_ABI_VERSION 4
+#define SKINRT_ABI_VERSION 5
 #define SKINRT_API __attribute__((visibility("default")))
 
 /* ---- error codes ---------------------------------------------------------------- */
@@ -296,7 +296,7 @@ SKINRT_API int skinrt_get_tangents(skinrt_crowd* crowd, float** out_dev, uint64_
 /* Per-instance bounds [I][2][3] f32 (min xyz, max xyz).  No reference counterpart (a14). */
 SKINRT_API int skinrt_get_aabbs(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
 /* Joint palette [I][J][24] f32: 3 rows x 4 of the joint matrix (row r = m[r][0..3] incl.
- * translation), then 3 rows x 4 of the normal matrix (4th of each row = 0).
+ * translation), then the 3 x 3 normal matrix row by row (9 floats, packed), then 3 floats of zero padding.
  * Same numbers as SkinMatrix (uniform/skin.rs:12-17), transposed to rows; see
  * skinrt_export_skin_uniform for the reference byte layout.
  * Sign of zero: the values compare equal (==) to glam's, but a zero in the normal rows may carry the other sign.

@@ -313,7 +313,15 @@ class Crowd:
         return self._fetch("aabbs", np.float32, (self.instances, 2, 3), first, count)
 
     def palette(self, first=0, count=None):
-        return self._fetch("palette", np.float32, (self.instances, self.rig.data.joint_count, 24), first, count)
+        """[count][J][24]: 3 rows x 4 of the joint matrix, then 3 rows x 4 of the normal matrix (4th of each row 0).  The
+        device buffer (skinrt_get_palette) keeps the nine normal entries packed; they are spread to padded rows here."""
+        dev = self._fetch("palette", np.float32, (self.instances, self.rig.data.joint_count, 24), first, count)
+        out = np.zeros_like(dev)
+        out[..., :12] = dev[..., :12]
+        for r in range(3):
+            out[..., 12 + 4 * r:15 + 4 * r] = dev[..., 12 + 3 * r:15 + 3 * r]
+        assert not dev[..., 21:].any(), "palette padding must be zero"
+        return out
 
     def world(self, first=0, count=None):
         return self._fetch("world", np.float32, (self.instances, self.rig.data.node_count, 12), first, count)

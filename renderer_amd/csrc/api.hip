@@ -599,7 +599,7 @@ int skinrt_export_skin_uniform(skinrt_crowd* c, uint32_t instance, void* dst) {
             o[col * 4 + 3] = col == 3 ? 1.0f : 0.0f;
         }
         for (int col = 0; col < 3; ++col) {  // normal: 3 columns padded with 0 (pad_vec3, :26-28)
-            for (int r = 0; r < 3; ++r) o[16 + col * 4 + r] = e[12 + r * 4 + col];
+            for (int r = 0; r < 3; ++r) o[16 + col * 4 + r] = e[12 + r * 3 + col];  // the nine entries are packed row by row
             o[16 + col * 4 + 3] = 0.0f;
         }
     }

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_export_interleaved(const ExportSrc src,
     }
 }
 
-// One thread per (instance, palette slot): 24 floats in (joint rows, normal rows), 28 floats out.
+// One thread per (instance, palette slot): 24 floats in (joint rows, packed normal rows, padding), 28 floats out.
 __global__ __launch_bounds__(256) void k_export_skin_uniform(const float* palette, uint32_t J, uint32_t first, uint32_t count, float4* dst) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g >= count * 128u) return;
@@ -90,9 +90,10 @@ __global__ __launch_bounds__(256) void k_export_skin_uniform(const float* palett
     o[1] = make_float4(r0.y, r1.y, r2.y, 0.0f);
     o[2] = make_float4(r0.z, r1.z, r2.z, 0.0f);
     o[3] = make_float4(r0.w, r1.w, r2.w, 1.0f);
-    o[4] = make_float4(n0.x, n1.x, n2.x, 0.0f);  // normal matrix columns, pad_vec3
-    o[5] = make_float4(n0.y, n1.y, n2.y, 0.0f);
-    o[6] = make_float4(n0.z, n1.z, n2.z, 0.0f);
+    // normal matrix columns, pad_vec3; the palette holds the nine entries packed row by row (n0 = n00 n01 n02 n10, ...)
+    o[4] = make_float4(n0.x, n0.w, n1.z, 0.0f);
+    o[5] = make_float4(n0.y, n1.x, n1.w, 0.0f);
+    o[6] = make_float4(n0.z, n1.y, n2.x, 0.0f);
 }
 
 }  // namespace

@@ -183,9 +183,10 @@ __device__ __forceinline__ void palette_entry(const Rows& world, const Rows& ibm
     const float rcp = 1.0f / dot1;
     float4* o = reinterpret_cast<float4*>(out24);
     o[0] = m.r0; o[1] = m.r1; o[2] = m.r2;
-    o[3] = make_float4(i00 * rcp, (-i01) * rcp, i02 * rcp, 0.0f);
-    o[4] = make_float4((-i10) * rcp, i11 * rcp, (-i12) * rcp, 0.0f);
-    o[5] = make_float4(i20 * rcp, (-i21) * rcp, i22 * rcp, 0.0f);
+    // normal rows packed: 9 floats, so that the skin kernels fetch them as 2 x 16 bytes + 4 bytes per influence
+    o[3] = make_float4(i00 * rcp, (-i01) * rcp, i02 * rcp, (-i10) * rcp);
+    o[4] = make_float4(i11 * rcp, (-i12) * rcp, i20 * rcp, (-i21) * rcp);
+    o[5] = make_float4(i22 * rcp, 0.0f, 0.0f, 0.0f);
 }
 
 __device__ __forceinline__ void clear_unused_keys(const RigDev& rig, uint32_t clip, bool has_clip,

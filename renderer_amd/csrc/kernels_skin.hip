@@ -38,11 +38,15 @@ __device__ unsigned long long g_stamps[16];
 #ifndef SKINRT_ABLATE
 #define SKINRT_ABLATE 0
 #endif
-// Timing experiments (results wrong): 2 = influence 0 takes its rows from registers (no LDS read), 4 = normal rows as 2 x b128 + b32,
+// Timing experiments (results wrong): 2 = influence 0 takes its rows from registers (no LDS read),
 // 8 = wave w of a block visits only (w + 1) * K influences (what sorting a tile's vertices by influence count would buy),
 // 16 = one influence per vertex.  (A further switch sent k_skin2's outputs through an LDS transposition and two block
 // barriers per instance, which sorted tiles would need for coalesced stores: +0.9 ms on C5, +0.5 ms on C3 — as much as
 // switch 8 saves; sorted tiles were not built.  tools/ubench/store_perm.hip: scattered 12-byte stores are 7x slower.)
+// influences whose palette rows are in flight together (a scheduling fence after every SKINRT_INFLIGHT-th)
+#ifndef SKINRT_INFLIGHT
+#define SKINRT_INFLIGHT 2
+#endif
 #ifndef SKINRT_EXP
 #define SKINRT_EXP 0
 #endif
@@ -158,7 +162,7 @@ __device__ __forceinline__ void blend_position(const Pal pal, const float (&w)[4
 #pragma unroll
         for (int x = 0; x < 12; ++x) S[x] = a == 0 ? mul_nc(w[0], m[x]) : madd<EXACT>(w[a], m[x], S[x]);
         // two influences' rows in flight at a time: bounds the live registers (5 waves per SIMD)
-        if ((a & 1) && a + 1 < 4 * K) __builtin_amdgcn_sched_barrier(0);
+        if ((a + 1) % SKINRT_INFLIGHT == 0 && a + 1 < 4 * K) __builtin_amdgcn_sched_barrier(0);
     }
 }
 template <bool EXACT>
@@ -180,15 +184,17 @@ __device__ __forceinline__ void blend_normal(const Pal pal, const float (&w)[4 *
         if (SKIP && a >= 4 && (a & 3) == 0 && (uint32_t)a >= ninf) break;  // wave-uniform, tested once per weight set
         if (((SKINRT_EXP & 8) && a > 0 && (uint32_t)a >= ninf) || ((SKINRT_EXP & 16) && a > 0)) break;
         const f4* e = pal.entry(li[a]);
-        f4 n0, n1, n2;
-        if ((SKINRT_EXP & 2) && a == 0) { n0 = f4{w[0], w[1], w[2], w[3]}; n1 = n0 * 2.0f; n2 = n0 * 3.0f; }
-        else if (SKINRT_EXP & 4) { n0 = e[3]; n1 = e[4]; n2 = f4{n0.w, n1.w, reinterpret_cast<const float*>(e + 5)[0], 0.0f}; }
-        else { n0 = e[3]; n1 = e[4]; n2 = e[5]; }  // full 16-byte rows: ds_read_b128, not the slower b96
-        const float q[9] = {n0.x, n0.y, n0.z, n1.x, n1.y, n1.z, n2.x, n2.y, n2.z};
-        if (!(SKINRT_EXP & 4)) asm volatile("" ::"v"(n0.w), "v"(n1.w), "v"(n2.w));
+        // the nine normal-matrix entries are packed (kernels_pose.hip: palette_entry): 2 x ds_read_b128 + ds_read_b32.
+        // An LDS read costs by the registers it fills (tools/ubench/lds_exec.hip), so this is 84 bytes per influence
+        // instead of the 96 of three padded rows (C5, which is bound by these reads: skin stage -0.4 ms).
+        f4 n0, n1;
+        float n22;
+        if ((SKINRT_EXP & 2) && a == 0) { n0 = f4{w[0], w[1], w[2], w[3]}; n1 = n0 * 2.0f; n22 = w[0]; }
+        else { n0 = e[3]; n1 = e[4]; n22 = reinterpret_cast<const float*>(e + 5)[0]; }
+        const float q[9] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n22};
 #pragma unroll
         for (int x = 0; x < 9; ++x) Nm[x] = a == 0 ? mul_nc(w[0], q[x]) : madd<EXACT>(w[a], q[x], Nm[x]);
-        if ((a & 1) && a + 1 < 4 * K) __builtin_amdgcn_sched_barrier(0);
+        if ((a + 1) % SKINRT_INFLIGHT == 0 && a + 1 < 4 * K) __builtin_amdgcn_sched_barrier(0);
     }
 }
 template <bool EXACT>
