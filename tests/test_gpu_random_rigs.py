@@ -70,3 +70,29 @@ def test_random_rig_fma_kernels_within_the_stated_tolerance(oracle32, case):
         assert_equal(got[k], ref[k], tag + k)
     for k in ("position", "normal", "tangent", "aabb"):
         assert_close(got[k], ref[k], tag + k)
+
+
+@pytest.mark.parametrize("case", range(150, 230))
+def test_random_rig_default_arithmetic_is_inside_the_stated_tolerance(oracle32, case):
+    """exact_arithmetic = 0: the library chooses per rig, and whatever it chooses — fused, or for rigs far from the origin
+    contraction-free positions with fused normals / tangents (skinrt_rig_info.exact_arithmetic = 2) — must be inside
+    1e-5 rel / 1e-6 abs with nothing widened, chains included; where it reports contraction-free positions they and the
+    bounds carry the oracle's bits."""
+    spec, cfg, instances, with_root = _draw(case)
+    cfg = dict(cfg, exact_arithmetic=0)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=instances, with_root=with_root)
+    got = run_gpu(rig, crowd, **cfg)
+    ref = run_oracle(oracle32, rig, crowd, cubic_quirk=cfg["cubic_quirk"], normalize_outputs=cfg["normalize_outputs"])
+    chosen = got["info"].exact_arithmetic
+    assert chosen in (0, 2)
+    tag = f"case {case} ({spec}, {cfg}, I={instances}, chosen {chosen}): "
+    for k in ("key_index", "world", "palette"):
+        assert_equal(got[k], ref[k], tag + k)
+    for k in ("position", "aabb"):
+        if chosen == 2:
+            assert_equal(got[k], ref[k], tag + k)
+        else:
+            assert_close(got[k], ref[k], tag + k)
+    for k in ("normal", "tangent"):
+        assert_close(got[k], ref[k], tag + k)
