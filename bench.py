@@ -46,7 +46,7 @@ def algorithmic_bytes(rig, instances):
     return instances * V * 36 + instances * (J * 84 + 4 * M) + V * (36 + 24 * K) + d
 
 
-def cpu_baseline(rig, spec, budget_s=12.0):
+def cpu_baseline(rig, spec, budget_s=15.0):
     """Oracle (fp32 C restatement, reference op order, -O2 -ffp-contract=off) timed on this
     box's host cores on a bounded sample of the same workload: single thread (the reference has
     one render thread, renderer/src/state.rs:236), then instance-parallel over 16 threads."""
@@ -61,7 +61,7 @@ def cpu_baseline(rig, spec, budget_s=12.0):
     t0 = time.perf_counter()
     orc.evaluate(rig, probe.tau, probe.clip_id, probe.morph_weights, want=want, desc=desc)
     per_inst = max((time.perf_counter() - t0) / 2, 1e-6)
-    n = int(max(2, min(spec.instances, budget_s / per_inst, 2.0e9 / (V * 36 + 1))))
+    n = int(max(2, min(spec.instances, budget_s / per_inst, 3.2e9 / (V * 36 + 1))))  # outputs of the sample: at most 3.2 GB of host memory
     crowd = synth.make_crowd(spec, rig, instances=n)
     res = OracleResult()
     t0 = time.perf_counter()

@@ -1,4 +1,4 @@
-//! Raw bindings of `include/skinrt.h` (ABI version 4), field for field and function for function.
+//! Raw bindings of `include/skinrt.h` (ABI version 5), field for field and function for function.
 //!
 //! `tests/test_rust_bindings.py` (CPU) parses the `#[repr(C)]` structs and the `extern "C"` block below, lays
 //! the structs out by the C rules and compares sizes, field offsets and the function list with what `gcc`
