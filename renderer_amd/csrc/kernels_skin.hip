@@ -47,6 +47,10 @@ __device__ unsigned long long g_stamps[16];
 #ifndef SKINRT_INFLIGHT
 #define SKINRT_INFLIGHT 2
 #endif
+#ifndef SKINRT_BLOCKS_K1
+#define SKINRT_BLOCKS_K1 5  // resident k_skin2 blocks per CU the register budget is set for, one weight set (measured: 6 blocks, which
+                            // need blocks of <= 64 instances and a one-instance lookahead to fit LDS: C3 4.43-4.54 ms against 4.38)
+#endif
 #ifndef SKINRT_EXP
 #define SKINRT_EXP 0
 #endif
@@ -1034,7 +1038,7 @@ __device__ __forceinline__ float wave_bounds_packed(const float (&v)[3], bool up
 constexpr uint32_t kSkin2Threads = 256;
 
 template <int AR, int K, int LOOK, bool SKIP>
-__global__ __launch_bounds__(kSkin2Threads, (K == 1 ? 5 : 4)) void k_skin2(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
+__global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) void k_skin2(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
