@@ -42,7 +42,11 @@ __device__ unsigned long long g_stamps[16];
 // 8 = wave w of a block visits only (w + 1) * K influences (what sorting a tile's vertices by influence count would buy),
 // 16 = one influence per vertex.  (A further switch sent k_skin2's outputs through an LDS transposition and two block
 // barriers per instance, which sorted tiles would need for coalesced stores: +0.9 ms on C5, +0.5 ms on C3 — as much as
-// switch 8 saves; sorted tiles were not built.  tools/ubench/store_perm.hip: scattered 12-byte stores are 7x slower.)
+// switch 8 saves; sorted tiles were not built.  tools/ubench/store_perm.hip: scattered 12-byte stores are 7x slower.
+// Another emulated a third morph pair per instance, fetched into registers by plain loads issued one instance ahead (before
+// the previous instance's last two stores) and waited for with vmcnt(3), for 1 in 23 instances — what taking C3's 3-pair
+// instances off k_skin_fix would cost k_skin2: +0.12 ms, plus their own 0.17 ms of work, against the 0.37 ms k_skin_fix
+// takes for them.  Not built either.)
 // influences whose palette rows are in flight together (a scheduling fence after every SKINRT_INFLIGHT-th)
 #ifndef SKINRT_INFLIGHT
 #define SKINRT_INFLIGHT 2
