@@ -190,7 +190,7 @@ class RigData:
         self.position = self.position.reshape(v, 3)
         self.normal = _arr(self.normal, np.float32, (v, 3))
         self.tangent = _arr(self.tangent, np.float32)
-        self.tangent = self.tangent.reshape(v, -1)
+        self.tangent = self.tangent.reshape(v, -1) if v else np.zeros((0, 3), np.float32)  # a skeleton without a mesh (pose only)
         self.joints = [_arr(a, np.uint16, (v, 4)) for a in self.joints]
         self.weights = [_arr(a, np.float32, (v, 4)) for a in self.weights]
         self.default_weights = _arr(self.default_weights, np.float32)

@@ -310,6 +310,24 @@ def test_edge_cases(oracle32):
     assert (got["key_index"][:2] == 0xFFFFFFFF).all()
 
 
+def test_skeleton_without_a_mesh(oracle32):
+    """Empty input on the vertex side: a rig of nodes, joints and clips with no vertices at all (what a caller that
+    only wants SkinUniformBuffer's palettes uploads).  Pose outputs equal the oracle, the vertex outputs are empty, and
+    the bounds of an empty mesh are the empty box (+inf, -inf) in the library as in the oracle."""
+    spec = synth.scaled(synth.tiny_spec(seed=5), verts=0, targets=0)
+    rig = synth.make_rig(spec)
+    assert rig.vertex_count == 0
+    crowd = synth.make_crowd(spec, rig, instances=5)
+    ref = run_oracle(oracle32, rig, crowd)
+    for stages in (abi.STAGE_POSE, abi.STAGE_ALL):
+        got = run_gpu(rig, crowd, stages=stages, want=("world", "palette", "key_index", "position", "aabb"))
+        for k in ("key_index", "world", "palette"):
+            assert_equal(got[k], ref[k], k)
+        assert got["position"].shape == (5, 0, 3)
+        if stages == abi.STAGE_ALL:
+            assert_equal(got["aabb"], ref["aabb"], "bounds of an empty mesh")
+
+
 def test_default_morph_weights_and_reset(oracle32):
     spec = synth.tiny_spec(seed=21)
     rig = synth.make_rig(spec)
