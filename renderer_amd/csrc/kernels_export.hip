@@ -22,27 +22,21 @@ struct ExportSrc {
     const float* weights0;   // [V][4]
 };
 
-// Block = 256 vertices of one instance.  The three output arrays and the shared per-vertex tables are read as
-// coalesced dword rows and scattered into the records' positions in LDS (S dwords per vertex, NA attribute dwords
-// after the position); the finished 256 records are one contiguous run of the destination, written back as 16-byte
-// pieces.  (A first version looked every destination dword up on its own, no LDS: 1.8 TB/s of read + written bytes.)
+// Block = 256 vertices x a group of kExportGroup consecutive instances.  The shared per-vertex tables (caller's colour /
+// texture coordinates, joint indices, weights) are scattered into the records' places in LDS ONCE per block; per instance
+// only the nine dwords of position / normal / tangent are rewritten (read as coalesced dword rows, the next instance's
+// already in flight while this one's records are written out), and the finished 256 records — one contiguous run of the
+// destination — go out as 16-byte streaming stores.  (History: every destination dword looked up on its own, no LDS:
+// 1.8 TB/s of read + written bytes; one instance per block, all fields re-scattered: 3.4-3.7 TB/s.)
+constexpr uint32_t kExportGroup = 8;
 template <uint32_t NA>
-__global__ __launch_bounds__(256) void k_export_interleaved(const ExportSrc src, uint32_t V, uint32_t tiles, uint32_t first, uint32_t* dst) {
+__global__ __launch_bounds__(256) void k_export_interleaved(const ExportSrc src, uint32_t V, uint32_t tiles, uint32_t first, uint32_t count, uint32_t* dst) {
     constexpr uint32_t S = 3 + NA + 3 + 3 + 2 + 4;
     __shared__ __align__(16) uint32_t rec[256 * S];
-    const uint32_t k = blockIdx.x / tiles, t = blockIdx.x - k * tiles, tid = threadIdx.x;
+    const uint32_t g = blockIdx.x / tiles, t = blockIdx.x - g * tiles, tid = threadIdx.x;
     const uint32_t v0 = t * 256, nv = min(256u, V - v0);
-    const size_t inst_off = (size_t)(first + k) * V * 3 + (size_t)v0 * 3;
+    const uint32_t k0 = g * kExportGroup, k1 = min(count, k0 + kExportGroup);
     // fields in dwords: position 0-2 | attr 3.. | normal 3+NA.. | tangent 6+NA.. | joint_index 9+NA (2) | joint_weight 11+NA (4)
-    const float* arrays[3] = {src.pos + inst_off, src.nrm + inst_off, src.tan + inst_off};
-    const uint32_t field[3] = {0u, 3u + NA, 6u + NA};
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const uint32_t d = tid + 256u * r;
-            if (d < nv * 3) rec[(d / 3) * S + field[a] + d % 3] = __float_as_uint(__builtin_nontemporal_load(arrays[a] + d));
-        }
 #pragma unroll
     for (uint32_t r = 0; r < NA; ++r) {
         const uint32_t d = tid + 256u * r;
@@ -58,17 +52,43 @@ __global__ __launch_bounds__(256) void k_export_interleaved(const ExportSrc src,
         const uint32_t d = tid + 256u * r;
         if (d < nv * 4) rec[(d / 4) * S + 11 + NA + d % 4] = __float_as_uint(src.weights0[(size_t)v0 * 4 + d]);
     }
-    __syncthreads();
-    const size_t out0 = ((size_t)k * V + v0) * S;  // dwords; v0 * S is a multiple of 4, k * V * S need not be
-    const uint32_t nd = nv * S;
-    uint32_t* out = dst + out0;
-    if ((out0 & 3u) == 0) {
-        // streaming stores: the records are written once and read by somebody else's kernels
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        for (uint32_t d = tid * 4; d + 4 <= nd; d += 1024) __builtin_nontemporal_store(*reinterpret_cast<const u4*>(rec + d), reinterpret_cast<u4*>(out + d));
-        if (tid < (nd & 3u)) out[(nd & ~3u) + tid] = rec[(nd & ~3u) + tid];
-    } else {
-        for (uint32_t d = tid; d < nd; d += 256) out[d] = rec[d];
+    const uint32_t field[3] = {0u, 3u + NA, 6u + NA};
+    uint32_t slot[3];  // where this thread's dword d = tid + 256 r of an array goes inside a record run (without the field offset)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { const uint32_t d = tid + 256u * r; slot[r] = (d / 3) * S + d % 3; }
+    float x[3][3];
+    auto fetch = [&](uint32_t k) {
+        const size_t inst_off = (size_t)(first + k) * V * 3 + (size_t)v0 * 3;
+        const float* arrays[3] = {src.pos + inst_off, src.nrm + inst_off, src.tan + inst_off};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const uint32_t d = tid + 256u * r;
+                x[a][r] = d < nv * 3 ? __builtin_nontemporal_load(arrays[a] + d) : 0.0f;
+            }
+    };
+    if (k0 < k1) fetch(k0);
+    for (uint32_t k = k0; k < k1; ++k) {
+        if (k != k0) __syncthreads();  // the previous instance's records have been read out of LDS
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                if (tid + 256u * r < nv * 3) rec[slot[r] + field[a]] = __float_as_uint(x[a][r]);
+        if (k + 1 < k1) fetch(k + 1);  // in flight while this instance's records go out
+        __syncthreads();
+        const size_t out0 = ((size_t)k * V + v0) * S;  // dwords; v0 * S is a multiple of 4, k * V * S need not be
+        const uint32_t nd = nv * S;
+        uint32_t* out = dst + out0;
+        if ((out0 & 3u) == 0) {
+            // streaming stores: the records are written once and read by somebody else's kernels
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            for (uint32_t d = tid * 4; d + 4 <= nd; d += 1024) __builtin_nontemporal_store(*reinterpret_cast<const u4*>(rec + d), reinterpret_cast<u4*>(out + d));
+            if (tid < (nd & 3u)) out[(nd & ~3u) + tid] = rec[(nd & ~3u) + tid];
+        } else {
+            for (uint32_t d = tid; d < nd; d += 256) out[d] = rec[d];
+        }
     }
 }
 
@@ -104,12 +124,13 @@ hipError_t launch_export_interleaved(const CrowdDev& cr, uint32_t V, const uint3
     if ((uint64_t)first + count > cr.I || (reinterpret_cast<uintptr_t>(dst) & 15u)) return hipErrorInvalidValue;
     const ExportSrc src{cr.pos, cr.nrm, cr.tan, attr, joints0, weights0};
     const uint32_t tiles = (V + 255) / 256;
-    if ((uint64_t)tiles * count > 0x7fffffffull) return hipErrorInvalidValue;
-    const dim3 grid(tiles * count), block(256);
+    const uint32_t groups = (count + kExportGroup - 1) / kExportGroup;
+    if ((uint64_t)tiles * groups > 0x7fffffffull) return hipErrorInvalidValue;
+    const dim3 grid(tiles * groups), block(256);
     if (layout == SKINRT_LAYOUT_COLOR_SKIN)
-        hipLaunchKernelGGL(k_export_interleaved<4>, grid, block, 0, s, src, V, tiles, first, static_cast<uint32_t*>(dst));
+        hipLaunchKernelGGL(k_export_interleaved<4>, grid, block, 0, s, src, V, tiles, first, count, static_cast<uint32_t*>(dst));
     else
-        hipLaunchKernelGGL(k_export_interleaved<2>, grid, block, 0, s, src, V, tiles, first, static_cast<uint32_t*>(dst));
+        hipLaunchKernelGGL(k_export_interleaved<2>, grid, block, 0, s, src, V, tiles, first, count, static_cast<uint32_t*>(dst));
     return hipGetLastError();
 }
 
