@@ -16,7 +16,8 @@
 //   S  = ((w0*M[j0] + w1*M[j1]) + w2*M[j2]) + w3*M[j3]   (further weight sets continue the chain)
 //   p' = ((S.c0*x + S.c1*y) + S.c2*z) + S.c3             n' = (N.c0*x + N.c1*y) + N.c2*z
 // EXACT=true: no FMA contraction -> bit-equal to the fp32 oracle.  EXACT=false (default): the
-// same association with fused multiply-adds; within 1e-5 rel / 1e-6 abs.
+// same association with fused multiply-adds; within 1e-5 rel / 1e-6 abs.  Rigs far from the origin get the
+// third form by default (AR = 2): positions contraction-free, normals / tangents fused.
 #include "device_types.hpp"
 
 namespace skinrt {
@@ -38,6 +39,14 @@ __device__ unsigned long long g_stamps[16];
 #ifndef SKINRT_ABLATE
 #define SKINRT_ABLATE 0
 #endif
+// influences whose palette rows are in flight together (a scheduling fence after every SKINRT_INFLIGHT-th; 1 / 3 / 4 / 8 measured: within noise)
+#ifndef SKINRT_INFLIGHT
+#define SKINRT_INFLIGHT 2
+#endif
+#ifndef SKINRT_BLOCKS_K1
+#define SKINRT_BLOCKS_K1 5  // resident k_skin2 blocks per CU the register budget is set for, one weight set (measured: 6 blocks, which
+                            // need blocks of <= 64 instances and a one-instance lookahead to fit LDS: C3 4.43-4.54 ms against 4.38)
+#endif
 // Timing experiments (results wrong): 2 = influence 0 takes its rows from registers (no LDS read),
 // 8 = wave w of a block visits only (w + 1) * K influences (what sorting a tile's vertices by influence count would buy),
 // 16 = one influence per vertex.  (A further switch sent k_skin2's outputs through an LDS transposition and two block
@@ -47,14 +56,6 @@ __device__ unsigned long long g_stamps[16];
 // the previous instance's last two stores) and waited for with vmcnt(3), for 1 in 23 instances — what taking C3's 3-pair
 // instances off k_skin_fix would cost k_skin2: +0.12 ms, plus their own 0.17 ms of work, against the 0.37 ms k_skin_fix
 // takes for them.  Not built either.)
-// influences whose palette rows are in flight together (a scheduling fence after every SKINRT_INFLIGHT-th)
-#ifndef SKINRT_INFLIGHT
-#define SKINRT_INFLIGHT 2
-#endif
-#ifndef SKINRT_BLOCKS_K1
-#define SKINRT_BLOCKS_K1 5  // resident k_skin2 blocks per CU the register budget is set for, one weight set (measured: 6 blocks, which
-                            // need blocks of <= 64 instances and a one-instance lookahead to fit LDS: C3 4.43-4.54 ms against 4.38)
-#endif
 #ifndef SKINRT_EXP
 #define SKINRT_EXP 0
 #endif
@@ -210,13 +211,12 @@ __device__ __forceinline__ void apply_normal(const float (&Nm)[9], const float (
                                              float (&on)[3], float (&ot)[3]) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        constexpr bool EX = EXACT;
         float a = mul_nc(Nm[3 * r], n[0]);
-        a = madd<EX>(Nm[3 * r + 1], n[1], a);
-        on[r] = madd<EX>(Nm[3 * r + 2], n[2], a);
+        a = madd<EXACT>(Nm[3 * r + 1], n[1], a);
+        on[r] = madd<EXACT>(Nm[3 * r + 2], n[2], a);
         float b = mul_nc(Nm[3 * r], t[0]);
-        b = madd<EX>(Nm[3 * r + 1], t[1], b);
-        ot[r] = madd<EX>(Nm[3 * r + 2], t[2], b);
+        b = madd<EXACT>(Nm[3 * r + 1], t[1], b);
+        ot[r] = madd<EXACT>(Nm[3 * r + 2], t[2], b);
     }
     if (normalize) {  // shader.wgsl:217-218 — v / sqrt(dot(v,v))
         const float ln = sqrtf(madd<true>(on[2], on[2], madd<true>(on[1], on[1], mul_nc(on[0], on[0]))));
