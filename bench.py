@@ -144,8 +144,8 @@ def spawn_ranks(n: int, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)  # the first 6-8 frames of a fresh crowd run up to 10 % slower
     ap.add_argument("--workload", default=None, choices=[None, "c2", "c3", "c4", "c5"])
     ap.add_argument("--instances", type=int, default=None, help="override the TOTAL instance count")
     ap.add_argument("--no-vertex-gather", action="store_true", help="N>1: skip the extra vertex all-gather measurement")
