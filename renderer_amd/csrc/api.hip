@@ -153,6 +153,10 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
         const uint32_t per = (T + tcs - 1) / tcs;
         if ((uint64_t)per * tcs * 100 <= (uint64_t)T * 104) { p.tile_chunks = tcs; break; }
     }
+    if (const char* ev = getenv("SKINRT_TILE_CHUNKS")) {  // experiments: 1, 2, 4 or 8 tile chunks (the other XCDs split the instance ranges)
+        const int v = atoi(ev);
+        if (v == 1 || v == 2 || v == 4 || v == 8) p.tile_chunks = (uint32_t)v;
+    }
     p.tiles_per_chunk = (T + p.tile_chunks - 1) / p.tile_chunks;
     const uint32_t rcs = 8 / p.tile_chunks;
     p.ranges_per_chunk = (std::max<uint32_t>(1, p.ranges) + rcs - 1) / rcs;
