@@ -56,6 +56,9 @@ __device__ unsigned long long g_stamps[16];
 // the previous instance's last two stores) and waited for with vmcnt(3), for 1 in 23 instances — what taking C3's 3-pair
 // instances off k_skin_fix would cost k_skin2: +0.12 ms, plus their own 0.17 ms of work, against the 0.37 ms k_skin_fix
 // takes for them.  Not built either.)
+#ifndef SKINRT_ORDER_ROT
+#define SKINRT_ORDER_ROT 23u  // k_skin2: a tile's instance order is rotated by tile * this (see the prologue; 0 / 1 / 7 / 13 / 23 measured)
+#endif
 #ifndef SKINRT_EXP
 #define SKINRT_EXP 0
 #endif
@@ -1119,13 +1122,20 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     const uint32_t nproc = nin - cnt_s[4] - cnt_s[5];  // instances this block processes itself
     // processing order: equal masks become neighbours (rank sort on distinct (mask, index) keys)
     if (tid < kSkin2Range) {
+        // Ties are broken by the instance's index ROTATED by a tile-dependent amount: neighbouring tiles then walk a
+        // range's instances out of phase, so the blocks in flight write to many instance rows at once instead of all to
+        // the same few (C3: 4.13 -> 4.00 ms with the morphs ablated, where every tile's order was the natural one; 1-1.5 % in
+        // the full build, whose orders already differ by their active-pair masks).  The result does not depend on the order.
+        const uint32_t rot = nin ? (tile * SKINRT_ORDER_ROT) % nin : 0u;
+        auto key = [&](uint32_t x) { return x < nin ? (x + rot < nin ? x + rot : x + rot - nin) : x; };
+        const uint32_t my_key = key(tid);
         uint32_t rank = 0;
         for (uint32_t j = 0; j < kSkin2Range; j += 4) {
             const uint4 mj = *reinterpret_cast<const uint4*>(mask_s + j);
-            rank += (mj.x < my_mask || (mj.x == my_mask && j + 0 < tid)) ? 1u : 0u;
-            rank += (mj.y < my_mask || (mj.y == my_mask && j + 1 < tid)) ? 1u : 0u;
-            rank += (mj.z < my_mask || (mj.z == my_mask && j + 2 < tid)) ? 1u : 0u;
-            rank += (mj.w < my_mask || (mj.w == my_mask && j + 3 < tid)) ? 1u : 0u;
+            rank += (mj.x < my_mask || (mj.x == my_mask && key(j + 0) < my_key)) ? 1u : 0u;
+            rank += (mj.y < my_mask || (mj.y == my_mask && key(j + 1) < my_key)) ? 1u : 0u;
+            rank += (mj.z < my_mask || (mj.z == my_mask && key(j + 2) < my_key)) ? 1u : 0u;
+            rank += (mj.w < my_mask || (mj.w == my_mask && key(j + 3) < my_key)) ? 1u : 0u;
         }
         perm_s[rank] = (uint16_t)tid;
     }
