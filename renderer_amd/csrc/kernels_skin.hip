@@ -1126,6 +1126,8 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
         // range's instances out of phase, so the blocks in flight write to many instance rows at once instead of all to
         // the same few (C3: 4.13 -> 4.00 ms with the morphs ablated, where every tile's order was the natural one; 1-1.5 % in
         // the full build, whose orders already differ by their active-pair masks).  The result does not depend on the order.
+        // (Starting the block's four WAVES at different points of the order as well: slower, 3.9 -> 4.1 ms ablated — the
+        // waves' four 768-byte pieces of an instance row want to be written together.)
         const uint32_t rot = nin ? (tile * SKINRT_ORDER_ROT) % nin : 0u;
         auto key = [&](uint32_t x) { return x < nin ? (x + rot < nin ? x + rot : x + rot - nin) : x; };
         const uint32_t my_key = key(tid);
