@@ -218,11 +218,18 @@ def main():
             pptr, _ = crowd.device_pointer(what)
             vert_t.append(torch.as_tensor(shard.DeviceArray(pptr, (mine, V * 3)), device=dev))
 
+    # The exchange step overlaps the next frame (shard.OverlappedRowGather: RCCL on a side stream behind an event of the
+    # library's stream; the next frame waits for a 24-byte-per-instance copy, never for the collective or the host).
+    # Rehearsed with one rank: a host synchronize plus the collective in line cost 0.19 ms of a 4.5 ms frame, the
+    # collective in line on the library's stream 0.16 ms, this form 0.01 ms.
+    exchange_step = shard.OverlappedRowGather(aabb_t, total, world, ctx.stream) if launched else None
+
     def step(gather=True):
+        if launched and gather:
+            exchange_step.before_frame()
         crowd.evaluate(abi.STAGE_ALL)
         if launched and gather:
-            ctx.synchronize()  # the library's stream -> torch's stream hand-off
-            shard.all_gather_rows(aabb_t, total, world)
+            exchange_step.after_frame()
 
     def fence():
         ctx.synchronize()

@@ -71,6 +71,61 @@ def all_gather_rows_chunked(tensors, instances: int, world: int, budget_bytes: i
     return moved
 
 
+class OverlappedRowGather:
+    """The per-frame exchange step: all-gather of one small per-instance array (the bounds, 24 B per
+    instance) that runs BESIDE the next frame instead of in front of it.  On a GPU the producer's stream (the library's,
+    passed as a raw hipStream_t and wrapped for torch without a copy) records an event when a frame is enqueued; a side
+    stream waits for it, copies the shard's rows into a staging buffer and all-gathers that (RCCL).  The next frame only
+    has to wait for the COPY (`before_frame`), never for the collective, and the host never blocks.  On the CPU (gloo,
+    the tests) there are no streams and the gather simply runs in `after_frame`.
+
+        ex = OverlappedRowGather(local_rows, instances, world, stream_ptr)
+        per frame:  ex.before_frame(); <enqueue the frame>; ex.after_frame()
+        ex.result()  ->  [instances, W] rows of the LAST frame (synchronises the side stream)"""
+
+    def __init__(self, local, instances: int, world: int, producer_stream: int = 0, group=None):
+        import torch
+
+        self.local, self.instances, self.world, self.group = local, instances, world, group
+        per = padded_count(instances, world)
+        width = tuple(local.shape[1:])
+        self.staging = torch.zeros((per,) + width, dtype=local.dtype, device=local.device)  # a short last shard stays zero-padded
+        self.gathered = torch.empty((world * per,) + width, dtype=local.dtype, device=local.device)
+        self.on_gpu = local.is_cuda
+        self.started = False
+        if self.on_gpu:
+            self.producer = torch.cuda.ExternalStream(producer_stream, device=local.device) if producer_stream else torch.cuda.current_stream(local.device)
+            self.side = torch.cuda.Stream(device=local.device)
+            self.ev_frame, self.ev_copy = torch.cuda.Event(), torch.cuda.Event()
+
+    def before_frame(self):
+        """the previous frame's rows have been copied out before this frame may rewrite them"""
+        if self.on_gpu and self.started:
+            self.producer.wait_event(self.ev_copy)
+
+    def after_frame(self):
+        import torch
+        import torch.distributed as dist
+
+        n = self.local.shape[0]
+        if not self.on_gpu:
+            self.staging[:n].copy_(self.local)
+            dist.all_gather_into_tensor(self.gathered, self.staging, group=self.group)
+        else:
+            self.ev_frame.record(self.producer)
+            self.side.wait_event(self.ev_frame)
+            with torch.cuda.stream(self.side):
+                self.staging[:n].copy_(self.local, non_blocking=True)
+                self.ev_copy.record(self.side)
+                dist.all_gather_into_tensor(self.gathered, self.staging, group=self.group)
+        self.started = True
+
+    def result(self):
+        if self.on_gpu:
+            self.side.synchronize()
+        return self.gathered[: self.instances]
+
+
 class DeviceArray:
     """Zero-copy view of a libskinrt device buffer for torch (`torch.as_tensor(DeviceArray(...),
     device='cuda')`), via __cuda_array_interface__."""

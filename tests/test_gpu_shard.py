@@ -40,6 +40,15 @@ with api.Context(device=0) as ctx:
     assert ga.data_ptr() != ap, "the collective must have produced a new buffer"
     assert np.array_equal(ga.cpu().numpy().view(np.uint32), c.aabbs().reshape(I, 6).view(np.uint32))
     assert np.array_equal(gp.cpu().numpy().view(np.uint32), c.positions().reshape(I, -1).view(np.uint32))
+    # the per-frame exchange object: RCCL on a side stream behind an event of the library's stream, three frames
+    # enqueued back to back with changing clocks and no host synchronisation in between; result() = the last frame's
+    ex = shard.OverlappedRowGather(a_t, I, 1, ctx.stream)
+    for frame in range(3):
+        c.set_clocks(crowd.tau * (0.5 + 0.25 * frame), crowd.clip_id)
+        ex.before_frame(); c.evaluate(abi.STAGE_ALL); ex.after_frame()
+    got = ex.result().cpu().numpy()
+    ctx.synchronize()
+    assert np.array_equal(got.view(np.uint32), c.aabbs().reshape(I, 6).view(np.uint32)), "overlapped gather of the last frame"
     c.close(); r.close()
 dist.destroy_process_group()
 print("RCCL_GATHER_OK")

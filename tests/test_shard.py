@@ -83,6 +83,15 @@ if rank == 0:
     assert np.array_equal(all_aabb.numpy().view(np.uint32), ref.aabb.reshape(I, 6).view(np.uint32))
     assert np.array_equal(all_pos.numpy().view(np.uint32), ref.position.view(np.uint32))
     print("GATHER_OK", I, world)
+# the per-frame exchange object of bench.py (on the CPU: no streams, the gather runs in after_frame), two frames in a row
+ex = shard.OverlappedRowGather(aabb, I, world)
+for frame in range(2):
+    ex.before_frame()
+    ex.after_frame()
+    if rank == 0:
+        assert np.array_equal(ex.result().numpy().view(np.uint32), ref.aabb.reshape(I, 6).view(np.uint32))
+if rank == 0:
+    print("OVERLAPPED_OK", I, world)
 # the chunked gather of several attributes through one bounded buffer (bench.py's vertex all-gather)
 per = shard.padded_count(I, world)
 flat = pos.reshape(hi - lo, V * 3)
@@ -118,3 +127,4 @@ def test_world_size_2_gather_is_byte_identical(instances, tmp_path):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert f"GATHER_OK {instances} 2" in p.stdout
     assert f"CHUNKED_OK {instances} 2" in p.stdout
+    assert f"OVERLAPPED_OK {instances} 2" in p.stdout
