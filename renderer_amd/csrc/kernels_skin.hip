@@ -1123,9 +1123,11 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     // processing order: equal masks become neighbours (rank sort on distinct (mask, index) keys)
     if (tid < kSkin2Range) {
         // Ties are broken by the instance's index ROTATED by a tile-dependent amount: neighbouring tiles then walk a
-        // range's instances out of phase, so the blocks in flight write to many instance rows at once instead of all to
-        // the same few (C3: 4.13 -> 4.00 ms with the morphs ablated, where every tile's order was the natural one; 1-1.5 % in
-        // the full build, whose orders already differ by their active-pair masks).  The result does not depend on the order.
+        // range's instances out of phase (C3: 4.13 -> 4.00 ms with the morphs ablated, where every tile's order was the
+        // natural one; 1-1.5 % in the full build, whose orders already differ by their active-pair masks).  The stores are
+        // not what gains — the store stream alone is indifferent to the phase (tools/ubench/store_phase.hip) — so it is the
+        // read side: in phase, every tile asks for the same instance's palette rows at the same moment.  The result does
+        // not depend on the order.
         // (Starting the block's four WAVES at different points of the order as well: slower, 3.9 -> 4.1 ms ablated — the
         // waves' four 768-byte pieces of an instance row want to be written together.)
         const uint32_t rot = nin ? (tile * SKINRT_ORDER_ROT) % nin : 0u;
