@@ -49,7 +49,8 @@ __device__ unsigned long long g_stamps[16];
 #endif
 // Timing experiments (results wrong): 2 = influence 0 takes its rows from registers (no LDS read),
 // 8 = wave w of a block visits only (w + 1) * K influences (what sorting a tile's vertices by influence count would buy),
-// 16 = one influence per vertex.  (A further switch sent k_skin2's outputs through an LDS transposition and two block
+// 16 = one influence per vertex, 1024 = k_skin2 requests no palette rows (stale LDS): C3 -0.25 ms, C5 -0.4 ms — what the
+// palette's way into LDS costs, four copies per tile and instance (one per wave).  (A further switch sent k_skin2's outputs through an LDS transposition and two block
 // barriers per instance, which sorted tiles would need for coalesced stores: +0.9 ms on C5, +0.5 ms on C3 — as much as
 // switch 8 saves; sorted tiles were not built.  tools/ubench/store_perm.hip: scattered 12-byte stores are 7x slower.
 // Another emulated a third morph pair per instance, fetched into registers by plain loads issued one instance ahead (before
@@ -1243,6 +1244,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     // the cell component this lane folds into (lanes 8k: see wave_bounds_packed): {-min x,y,z, +max x,y,z} = components 0 .. 5
     const uint32_t bb_lane = bb_lds + ((0x21205453u >> ((lane >> 3) * 4)) & 7u) * 4;
     auto pal_dma = [&](uint32_t inst, uint32_t slot) {  // request one instance's palette rows into ring slot `slot`
+        if (SKINRT_EXP & 1024) return;  // timing experiment: no palette reads at all (stale LDS)
         const char* gbase = pal_g + (size_t)inst * pal_stride;
         const uint32_t lds0 = ring_lds + slot * pal_slot_f * 4;
         if (lane < npieces) SKINRT_GLDS_AT(joff0, gbase, lds0);
