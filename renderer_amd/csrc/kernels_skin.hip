@@ -731,8 +731,11 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
 // Instances that need more than the two slots go to k_skin_fix.  Tiles with more than 21 joints
 // (their palette pieces do not fit two DMA instructions) and rigs with 3-4 weight sets stay on k_skin.
 
+#ifndef SKINRT_PAL_MOD
+#define SKINRT_PAL_MOD ""  // cache policy of the palette requests (" nt", " sc1", " sc0 sc1" measured: see profiles/r02_ubench.txt)
+#endif
 #define SKINRT_GLDS_AT(VOFF, GBASE, LDSB)                                                               \
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                       \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" SKINRT_PAL_MOD           \
                  : : "v"(VOFF), "s"(GBASE), "s"(LDSB) : "memory")
 
 template <int N>
