@@ -1,4 +1,4 @@
-//! Raw bindings of `include/skinrt.h` (ABI version 5), field for field and function for function.
+//! Raw bindings of `include/skinrt.h` (ABI version 6), field for field and function for function.
 //!
 //! `tests/test_rust_bindings.py` (CPU) parses the `#[repr(C)]` structs and the `extern "C"` block below, lays
 //! the structs out by the C rules and compares sizes, field offsets and the function list with what `gcc`
@@ -10,11 +10,13 @@
 //!   skinrt_clip_desc          AnimationAsset                                                  renderer-asset/src/animation.rs:36-40
 //!   skinrt_morph_target_desc  PrimitiveAssetMorphTarget                                       renderer-asset/src/primitive.rs:33-38
 //!   skinrt_rig_desc           NodeAsset tree + SkinAsset + PrimitiveAssetAttributes           node.rs:89-99, skin.rs:5-11, primitive.rs:22-31
+//!   skinrt_skin_desc          SkinAsset (one per glTF skin, shared by Arc)                    renderer-asset/src/skin.rs:5-11
+//!   skinrt_section_desc       a NodeAsset with mesh: Some(..), its skin or none               renderer-asset/src/node.rs:89-99
 #![allow(non_camel_case_types)]
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const SKINRT_ABI_VERSION: c_int = 5;
+pub const SKINRT_ABI_VERSION: c_int = 6;
 
 pub const SKINRT_OK: c_int = 0;
 pub const SKINRT_E_INVALID: c_int = -1;
@@ -41,6 +43,11 @@ pub const SKINRT_LAYOUT_COLOR_SKIN: u32 = 0;
 pub const SKINRT_LAYOUT_TEXTURE_SKIN: u32 = 1;
 pub const SKINRT_MAX_JOINTS_REFERENCE: u32 = 128;
 pub const SKINRT_SKIN_MATRIX_BYTES: usize = 112;
+pub const SKINRT_INSTANCE_UNIFORM_BYTES: usize = 124;
+pub const SKINRT_BUILD_ABLATE: u32 = 1;
+pub const SKINRT_BUILD_EXP: u32 = 2;
+pub const SKINRT_BUILD_STAMPS: u32 = 4;
+pub const SKINRT_BUILD_TUNING: u32 = 8;
 pub const SKINRT_TANGENT_NOALLOC_MAX_VERTICES: u32 = 262_144;
 pub const SKINRT_TANGENT_NOALLOC_MAX_INDICES: u32 = 1_572_864;
 
@@ -73,6 +80,7 @@ pub struct skinrt_config {
     pub pose_path: u32,
     pub skin_path: u32,
     pub output_placement: u32,
+    pub allow_experimental_build: u32,
 }
 
 #[repr(C)]
@@ -106,6 +114,25 @@ pub struct skinrt_morph_target_desc {
 
 #[repr(C)]
 #[derive(Debug, Clone, Copy)]
+pub struct skinrt_skin_desc {
+    pub joint_count: u32,
+    pub joint_node: *const u32,
+    pub inverse_bind: *const f32,
+}
+
+#[repr(C)]
+#[derive(Debug, Clone, Copy, Default)]
+pub struct skinrt_section_desc {
+    pub node: u32,
+    pub skin: i32,
+    pub first_vertex: u32,
+    pub vertex_count: u32,
+    pub first_target: u32,
+    pub target_count: u32,
+}
+
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
 pub struct skinrt_rig_desc {
     pub struct_size: u32,
     pub node_count: u32,
@@ -131,6 +158,10 @@ pub struct skinrt_rig_desc {
     pub target_count: u32,
     pub targets: *const skinrt_morph_target_desc,
     pub default_weights: *const f32,
+    pub skin_count: u32,
+    pub skins: *const skinrt_skin_desc,
+    pub section_count: u32,
+    pub sections: *const skinrt_section_desc,
 }
 
 #[repr(C)]
@@ -154,6 +185,30 @@ pub struct skinrt_rig_info {
     pub bind_extent: f32,
     pub weight_channel_clips: u32,
     pub skip_weight_sets: u32,
+    pub skin_count: u32,
+    pub section_count: u32,
+    pub palette_count: u32,
+    pub reserved: u32,
+}
+
+#[repr(C)]
+#[derive(Debug, Clone, Copy, Default)]
+pub struct skinrt_skin_layout {
+    pub first_palette_entry: u32,
+    pub joint_count: u32,
+}
+
+#[repr(C)]
+#[derive(Debug, Clone, Copy, Default)]
+pub struct skinrt_section_layout {
+    pub node: u32,
+    pub skin: i32,
+    pub first_vertex: u32,
+    pub vertex_count: u32,
+    pub first_target: u32,
+    pub target_count: u32,
+    pub first_palette_entry: u32,
+    pub reserved: u32,
 }
 
 #[repr(C)]
@@ -170,6 +225,7 @@ pub struct skinrt_placement_info {
 
 extern "C" {
     pub fn skinrt_abi_version() -> c_int;
+    pub fn skinrt_build_flags() -> u32;
     pub fn skinrt_last_error() -> *const c_char;
 
     pub fn skinrt_init(config: *const skinrt_config, out_ctx: *mut *mut skinrt_ctx) -> c_int;
@@ -178,6 +234,8 @@ extern "C" {
     pub fn skinrt_validate_rig(config: *const skinrt_config, desc: *const skinrt_rig_desc, out_info: *mut skinrt_rig_info) -> c_int;
     pub fn skinrt_destroy_rig(rig: *mut skinrt_rig) -> c_int;
     pub fn skinrt_get_rig_info(rig: *mut skinrt_rig, out_info: *mut skinrt_rig_info) -> c_int;
+    pub fn skinrt_rig_skin_layout(rig: *mut skinrt_rig, skin: u32, out: *mut skinrt_skin_layout) -> c_int;
+    pub fn skinrt_rig_section_layout(rig: *mut skinrt_rig, section: u32, out: *mut skinrt_section_layout) -> c_int;
     pub fn skinrt_create_crowd(ctx: *mut skinrt_ctx, rig: *mut skinrt_rig, instances: u32, out_crowd: *mut *mut skinrt_crowd) -> c_int;
     pub fn skinrt_destroy_crowd(crowd: *mut skinrt_crowd) -> c_int;
     pub fn skinrt_get_output_placement(crowd: *mut skinrt_crowd, out_info: *mut skinrt_placement_info) -> c_int;
@@ -185,6 +243,9 @@ extern "C" {
     pub fn skinrt_shard_range(instances: u32, rank: u32, world: u32, out_first: *mut u32, out_count: *mut u32) -> c_int;
 
     pub fn skinrt_set_clocks(crowd: *mut skinrt_crowd, tau: *const f32, clip_id: *const u32) -> c_int;
+    pub fn skinrt_set_clocks_async(crowd: *mut skinrt_crowd, tau: *const f32, clip_id: *const u32) -> c_int;
+    pub fn skinrt_advance_clocks(crowd: *mut skinrt_crowd, dt: f32, dev_rate: *const f32) -> c_int;
+    pub fn skinrt_get_clocks(crowd: *mut skinrt_crowd, out_dev: *mut *mut f32, out_count: *mut u64) -> c_int;
     pub fn skinrt_set_morph_weights(crowd: *mut skinrt_crowd, weights: *const f32) -> c_int;
     pub fn skinrt_set_root_transforms(crowd: *mut skinrt_crowd, matrices: *const f32) -> c_int;
 
@@ -204,6 +265,15 @@ extern "C" {
 
     pub fn skinrt_export_skin_uniform(crowd: *mut skinrt_crowd, instance: u32, dst: *mut c_void) -> c_int;
     pub fn skinrt_export_interleaved(crowd: *mut skinrt_crowd, instance: u32, layout: u32, attr: *const f32, dst: *mut c_void) -> c_int;
+    pub fn skinrt_export_skin_uniform_of(crowd: *mut skinrt_crowd, skin: u32, instance: u32, dst: *mut c_void) -> c_int;
+    pub fn skinrt_export_interleaved_section(crowd: *mut skinrt_crowd, section: u32, instance: u32, layout: u32, attr: *const f32,
+                                             dst: *mut c_void) -> c_int;
+    pub fn skinrt_export_instance_uniform(crowd: *mut skinrt_crowd, instance: u32, node: u32, dst: *mut c_void) -> c_int;
+    pub fn skinrt_export_skin_uniform_of_device(crowd: *mut skinrt_crowd, skin: u32, first: u32, count: u32, dev_dst: *mut c_void) -> c_int;
+    pub fn skinrt_export_interleaved_section_device(crowd: *mut skinrt_crowd, section: u32, first: u32, count: u32, layout: u32,
+                                                    dev_attr: *const f32, dev_dst: *mut c_void) -> c_int;
+    pub fn skinrt_export_instance_uniform_device(crowd: *mut skinrt_crowd, first: u32, count: u32, dev_nodes: *const u32, node_count: u32,
+                                                 stride: u32, dev_dst: *mut c_void) -> c_int;
     pub fn skinrt_export_skin_uniform_device(crowd: *mut skinrt_crowd, first: u32, count: u32, dev_dst: *mut c_void) -> c_int;
     pub fn skinrt_export_interleaved_device(crowd: *mut skinrt_crowd, first: u32, count: u32, layout: u32, dev_attr: *const f32,
                                             dev_dst: *mut c_void) -> c_int;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SKINRT_ABI_VERSION 5
+#define SKINRT_ABI_VERSION 6
 #define SKINRT_API __attribute__((visibility("default")))
 
 /* ---- error codes ---------------------------------------------------------------- */
@@ -70,6 +70,15 @@ extern "C" {
 
 #define SKINRT_MAX_JOINTS_REFERENCE 128 /* MAX_JOINTS, renderer/src/renderer/uniform/skin.rs:10 */
 #define SKINRT_SKIN_MATRIX_BYTES 112    /* SkinMatrix{[[f32;4];4],[[f32;4];3]}, uniform/skin.rs:12-17 */
+#define SKINRT_INSTANCE_UNIFORM_BYTES 124 /* InstanceUniform{[[f32;4];4],[[f32;4];3],[u8;12]}, uniform/transform.rs:8-14 */
+
+/* skinrt_build_flags(): what the loaded library was compiled with.  0 = the product.  Any other bit marks a
+ * measurement build whose RESULTS MAY BE WRONG BY DESIGN (kernels_skin.hip ablation switches); skinrt_init refuses
+ * to create a context on such a library unless skinrt_config.allow_experimental_build is set. */
+#define SKINRT_BUILD_ABLATE 1u   /* -DSKINRT_ABLATE=... : parts of the skin kernels removed */
+#define SKINRT_BUILD_EXP 2u      /* -DSKINRT_EXP=...    : experimental variants of the skin kernels */
+#define SKINRT_BUILD_STAMPS 4u   /* -DSKINRT_STAMPS     : in-kernel cycle stamps */
+#define SKINRT_BUILD_TUNING 8u   /* non-default SKINRT_RANGE2 / SKINRT_MORPH_SLOTS / SKINRT_PALETTE_* compile-time tuning */
 
 typedef struct skinrt_ctx skinrt_ctx;
 typedef struct skinrt_rig skinrt_rig;
@@ -112,6 +121,8 @@ typedef struct skinrt_config {
      * the duration of skinrt_create_crowd), and the result is measured (skinrt_get_output_placement).
      * 1: three plain hipMalloc calls, no filler, no measurement. */
     uint32_t output_placement;
+    /* 1: skinrt_init accepts a library whose skinrt_build_flags() is not 0 (measurement builds). */
+    uint32_t allow_experimental_build;
 } skinrt_config;
 
 /* ---- flat rig ("loader output", SURVEY.md §8a rows a1,a5-a8,a11,a13) ---------------- */
@@ -128,11 +139,13 @@ typedef struct skinrt_channel_desc {
     /* width w = 4 for rotation (x,y,z,w), 3 for translation / scale, the rig's target_count for weights.
      * LINEAR/STEP: [key_count][w].  CUBICSPLINE: [key_count][3][w] = (in, value, out),
      * the order of AnimationKeyFrames::CubicSpline (animation.rs:18-19).
-     * SKINRT_PATH_WEIGHTS: at most one such channel per clip (the rig has one morphed mesh; target_node names
-     * its node and is otherwise unused: the channel does not turn a Matrix node into TRS form).  An instance
-     * playing a clip with a weights channel takes its morph weights w[M] from the channel's sample at tau, in
-     * place of skinrt_set_morph_weights / the rig's defaults, which keep applying to every other instance.
-     * The sampled weights are produced by SKINRT_STAGE_POSE and consumed by SKINRT_STAGE_SKIN. */
+     * SKINRT_PATH_WEIGHTS: width = the target_count of the mesh section whose node is target_node (at most one such
+     * channel per clip and section; with no sections[] the rig is one section and target_node is not looked at).
+     * The channel does not turn a Matrix node into TRS form.  An instance playing a clip with a weights channel
+     * takes that section's morph weights from the channel's sample at tau, in place of skinrt_set_morph_weights /
+     * the rig's defaults, which keep applying to every other instance and section.  The sampled weights are
+     * refreshed by SKINRT_STAGE_POSE — and by a SKINRT_STAGE_SKIN that follows skinrt_set_morph_weights /
+     * skinrt_set_clocks without a pose stage in between — and consumed by SKINRT_STAGE_SKIN. */
     const float* values;
 } skinrt_channel_desc;
 
@@ -142,9 +155,11 @@ typedef struct skinrt_clip_desc {
     const skinrt_channel_desc* channels;
 } skinrt_clip_desc;
 
-/* One PrimitiveAssetMorphTarget{position,normal,tangent} — renderer-asset/src/primitive.rs:33-38.
- * indices == NULL: dense, count == vertex_count (the loader's form).  indices != NULL:
- * compacted form, arrays hold only the touched vertices (strictly increasing indices). */
+/* One PrimitiveAssetMorphTarget{position,normal,tangent} — renderer-asset/src/primitive.rs:33-38 (the same target
+ * of every primitive of a mesh, concatenated).  A target belongs to the section whose [first_target,
+ * first_target + target_count) holds it and moves that section's vertices only; rows and indices count from the
+ * section's first_vertex.  indices == NULL: dense, count == the section's vertex_count (the loader's form).
+ * indices != NULL: compacted form, arrays hold only the touched vertices (strictly increasing indices). */
 typedef struct skinrt_morph_target_desc {
     uint32_t count;
     const uint32_t* indices;
@@ -152,6 +167,29 @@ typedef struct skinrt_morph_target_desc {
     const float* normal;     /* [count][3], NULL = zeros */
     const float* tangent;    /* [count][tangent_stride], NULL = zeros; only xyz is used */
 } skinrt_morph_target_desc;
+
+/* One SkinAsset{inverse_bind_matrices,joint_ids} — renderer-asset/src/skin.rs:5-11.  The loader caches skins per
+ * glTF skin index and nodes share them by Arc (loader/gltf/mod.rs:1124-1166, node.rs:95): an avatar normally has
+ * several skins (body / face / hair) over one node tree. */
+typedef struct skinrt_skin_desc {
+    uint32_t joint_count;
+    const uint32_t* joint_node;  /* [joint_count] flat node index of each joint */
+    const float* inverse_bind;   /* [joint_count][16] or NULL = identity (loader/gltf/mod.rs:1139-1145) */
+} skinrt_skin_desc;
+
+/* One mesh instance: a NodeAsset with mesh: Some(..) (renderer-asset/src/node.rs:89-99), all primitives of its
+ * MeshAsset concatenated (mesh.rs:4-8).  skin >= 0: NodeAsset.skin, the section's JOINTS_n index that skin's joints
+ * and its node transform is ignored, as the skin shaders do (shader.wgsl:154-165).  skin = -1: NodeAsset.skin == None,
+ * an un-skinned mesh: its vertices are placed by the node's world matrix exactly as the non-skin shaders place them,
+ * instance.transform * vec4(position, 1), instance.normal * normal / tangent (shader.wgsl:143-152, :167-176), with
+ * instance.normal = Mat3(inverse(transform)^T) (uniform/transform.rs:27-34); joints[] / weights[] are not read for
+ * its vertices.  Sections tile [0, vertex_count) and [0, target_count) in order, without gaps. */
+typedef struct skinrt_section_desc {
+    uint32_t node;            /* flat node index of the NodeAsset that carries the mesh */
+    int32_t skin;             /* index into skins[], or -1 */
+    uint32_t first_vertex, vertex_count;
+    uint32_t first_target, target_count;  /* the mesh's morph targets (MeshAsset.weights.len()) */
+} skinrt_section_desc;
 
 typedef struct skinrt_rig_desc {
     uint32_t struct_size;    /* = sizeof(skinrt_rig_desc) */
@@ -166,7 +204,8 @@ typedef struct skinrt_rig_desc {
     const float* matrix;         /* [N][16] or NULL; NodeTransform::Matrix (node.rs:29-33) */
     const uint8_t* has_matrix;   /* [N] or NULL; 1 = node uses matrix[n] */
 
-    /* skin: SkinAsset{inverse_bind_matrices,joint_ids} — renderer-asset/src/skin.rs:5-11 */
+    /* skin: SkinAsset{inverse_bind_matrices,joint_ids} — renderer-asset/src/skin.rs:5-11.  The single-skin
+     * short form: read only when skin_count == 0 below (then this is skin 0). */
     uint32_t joint_count;
     const uint32_t* joint_node;  /* [J] flat node index of each joint */
     const float* inverse_bind;   /* [J][16] or NULL = identity (loader/gltf/mod.rs:1139-1145) */
@@ -190,6 +229,14 @@ typedef struct skinrt_rig_desc {
     uint32_t target_count;
     const skinrt_morph_target_desc* targets;
     const float* default_weights;   /* [M] or NULL = zeros */
+
+    /* several skins on one node tree, several meshes (ABI 6).  skin_count == 0: one skin, the short form above.
+     * section_count == 0: one section = all vertices, all targets, skin 0 (or, without joints, nothing to skin).
+     * With sections, joints[k][v] index the joints of the vertex's OWN skin, as the loader delivers them. */
+    uint32_t skin_count;
+    const skinrt_skin_desc* skins;
+    uint32_t section_count;
+    const skinrt_section_desc* sections;
 } skinrt_rig_desc;
 
 /* ---- rig introspection (what upload compiled; used by tests and the bench roofline) ------- */
@@ -209,7 +256,23 @@ typedef struct skinrt_rig_info {
     /* 1: enough 64-vertex waves of the mesh have all-zero weights in the second weight set that the skin stage runs
      *    the kernels which let such a wave stop after the first set (same results: the skipped terms are 0 * M) */
     uint32_t skip_weight_sets;
+    /* ABI 6.  The palette holds every skin's joints one skin after the other, then one entry per distinct node of an
+     * un-skinned section (joint matrix = the node's world matrix): palette_count = sum of joint counts + those. */
+    uint32_t skin_count, section_count, palette_count;
+    uint32_t reserved;
 } skinrt_rig_info;
+
+/* Where a skin / a section lives in the crowd's arrays (skinrt_rig_skin_layout, skinrt_rig_section_layout). */
+typedef struct skinrt_skin_layout {
+    uint32_t first_palette_entry, joint_count;
+} skinrt_skin_layout;
+typedef struct skinrt_section_layout {
+    uint32_t node;
+    int32_t skin;
+    uint32_t first_vertex, vertex_count, first_target, target_count;
+    uint32_t first_palette_entry;   /* skinned: its skin's; un-skinned: the entry holding the node's world matrix */
+    uint32_t reserved;
+} skinrt_section_layout;
 
 /* What skinrt_create_crowd did with the output arrays and what it measured (all zero for small crowds
  * and for output_placement=1). */
@@ -227,6 +290,8 @@ typedef struct skinrt_placement_info {
 
 /* Library/ABI version (SKINRT_ABI_VERSION). No reference counterpart. */
 SKINRT_API int skinrt_abi_version(void);
+/* SKINRT_BUILD_* bits the library was compiled with; 0 for the product. No reference counterpart. */
+SKINRT_API uint32_t skinrt_build_flags(void);
 
 /* Text of the last error raised on the calling thread ("" if none).
  * Stands in for GltfLoaderError's Display impl (loader/gltf/mod.rs:78-173). */
@@ -247,6 +312,10 @@ SKINRT_API int skinrt_validate_rig(const skinrt_config* config, const skinrt_rig
 SKINRT_API int skinrt_destroy_rig(skinrt_rig* rig);
 /* What skinrt_upload_rig compiled for this rig. No reference counterpart. */
 SKINRT_API int skinrt_get_rig_info(skinrt_rig* rig, skinrt_rig_info* out_info);
+/* Where skin `skin` / section `section` of the rig lie in the palette, vertex and morph-weight arrays
+ * (SkinAsset: skin.rs:5-11; NodeAsset.mesh: node.rs:96).  SKINRT_E_RANGE beyond the rig's counts. */
+SKINRT_API int skinrt_rig_skin_layout(skinrt_rig* rig, uint32_t skin, skinrt_skin_layout* out);
+SKINRT_API int skinrt_rig_section_layout(skinrt_rig* rig, uint32_t section, skinrt_section_layout* out);
 
 /* Allocate per-instance state and output buffers for `instances` copies of `rig`.
  * Replaces one SkinUniformBuffer::new per entity (renderer/uniform/skin.rs:39-57). */
@@ -267,6 +336,20 @@ SKINRT_API int skinrt_shard_range(uint32_t instances, uint32_t rank, uint32_t wo
 /* Per-instance animation clock tau[I] (seconds, already wrapped by the caller) and clip
  * index clip_id[I] (NULL = clip 0; UINT32_MAX = rest pose).  Keyframe search rule: SURVEY.md §8a a4. */
 SKINRT_API int skinrt_set_clocks(skinrt_crowd* crowd, const float* tau, const uint32_t* clip_id);
+/* The same without blocking the host (a frame loop that never drains the GPU; renderer/src/state.rs:236-330 is one
+ * thread that would otherwise stall here every frame).  tau / clip_id are DEVICE pointers, or host memory the GPU
+ * can read (hipHostMalloc), and must stay unchanged until the copy — enqueued on the ctx stream, in order with the
+ * evaluates around it — has run.  clip_id NULL keeps the current clips.  Nothing is validated on the host: a clip id
+ * >= clip_count plays the rest pose, like UINT32_MAX.  No reference counterpart. */
+SKINRT_API int skinrt_set_clocks_async(skinrt_crowd* crowd, const float* tau, const uint32_t* clip_id);
+/* Advance every instance's clock on the device, stream-ordered, no host data:
+ *   tau[i] = fmodf(tau[i] + dt * rate[i], clip_length[clip[i]])      (two roundings, then the exact remainder)
+ * — the wrap SURVEY.md §8a a4 leaves to the caller — with clip_length = the largest key time of the clip
+ * (AnimationChannelAsset.length, loader/gltf/mod.rs:1243-1247); dev_rate is a DEVICE array [I] or NULL = 1.0;
+ * instances at rest (clip id out of range) and clips of length 0 keep their clock.  No reference counterpart. */
+SKINRT_API int skinrt_advance_clocks(skinrt_crowd* crowd, float dt, const float* dev_rate);
+/* The clocks as they are now, [I] f32 device pointer (skinrt_download copies them out). */
+SKINRT_API int skinrt_get_clocks(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
 /* Per-instance morph weights w[I][M] (NodeAsset.weights override, node.rs:98); NULL restores
  * the rig's default weights for every instance. */
 SKINRT_API int skinrt_set_morph_weights(skinrt_crowd* crowd, const float* weights);
@@ -295,7 +378,7 @@ SKINRT_API int skinrt_get_normals(skinrt_crowd* crowd, float** out_dev, uint64_t
 SKINRT_API int skinrt_get_tangents(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
 /* Per-instance bounds [I][2][3] f32 (min xyz, max xyz).  No reference counterpart (a14). */
 SKINRT_API int skinrt_get_aabbs(skinrt_crowd* crowd, float** out_dev, uint64_t* out_count);
-/* Joint palette [I][J][24] f32: 3 rows x 4 of the joint matrix (row r = m[r][0..3] incl.
+/* Joint palette [I][P][24] f32, P = skinrt_rig_info.palette_count (one skin: J): 3 rows x 4 of the joint matrix (row r = m[r][0..3] incl.
  * translation), then the 3 x 3 normal matrix row by row (9 floats, packed), then 3 floats of zero padding.
  * Same numbers as SkinMatrix (uniform/skin.rs:12-17), transposed to rows; see
  * skinrt_export_skin_uniform for the reference byte layout.
@@ -325,6 +408,20 @@ SKINRT_API int skinrt_export_skin_uniform(skinrt_crowd* crowd, uint32_t instance
 SKINRT_API int skinrt_export_interleaved(skinrt_crowd* crowd, uint32_t instance, uint32_t layout,
                               const float* attr, void* dst);
 
+/* The two exports above for one skin / one section of a rig with several (ABI 6): `skin`'s joints as
+ * 128 x SkinMatrix; `section`'s vertices (section.vertex_count records), joint_index / joint_weight = the
+ * section's own set-0 indices (into its skin's joints) and weights.  SKINRT_E_INVALID for an un-skinned section:
+ * the reference draws those from the static mesh and an InstanceUniform (below). */
+SKINRT_API int skinrt_export_skin_uniform_of(skinrt_crowd* crowd, uint32_t skin, uint32_t instance, void* dst);
+SKINRT_API int skinrt_export_interleaved_section(skinrt_crowd* crowd, uint32_t section, uint32_t instance, uint32_t layout,
+                                                 const float* attr, void* dst);
+/* InstanceUniform{transform: [[f32;4];4], normal: [[f32;4];3], padding: [u8;12]} of node `node` of instance
+ * `instance` — what InstanceUniformBuffer::update writes (renderer/src/renderer/uniform/transform.rs:8-14, :51-59)
+ * with transform = the node's world matrix, normal = Mat3::from_mat4(transform.inverse().transpose()) (:27-34), the
+ * uniform the non-skin shaders read (shader.wgsl:56-61, :143-152).  dst: 124 bytes.  Zero signs as at
+ * skinrt_get_palette. */
+SKINRT_API int skinrt_export_instance_uniform(skinrt_crowd* crowd, uint32_t instance, uint32_t node, void* dst);
+
 /* ---- reference-layout exports on the device (whole instance ranges, device destinations) ------ */
 /* The two exports above for instances [first, first + count) in ONE kernel each, written straight from the
  * crowd's output arrays to device memory the caller owns (what a render core would bind as vertex / uniform
@@ -337,6 +434,18 @@ SKINRT_API int skinrt_export_interleaved(skinrt_crowd* crowd, uint32_t instance,
 SKINRT_API int skinrt_export_skin_uniform_device(skinrt_crowd* crowd, uint32_t first, uint32_t count, void* dev_dst);
 SKINRT_API int skinrt_export_interleaved_device(skinrt_crowd* crowd, uint32_t first, uint32_t count, uint32_t layout,
                                      const float* dev_attr, void* dev_dst);
+/* The same for one skin / one section (see skinrt_export_skin_uniform_of, skinrt_export_interleaved_section);
+ * dev_attr is [section.vertex_count][4 or 2]. */
+SKINRT_API int skinrt_export_skin_uniform_of_device(skinrt_crowd* crowd, uint32_t skin, uint32_t first, uint32_t count, void* dev_dst);
+SKINRT_API int skinrt_export_interleaved_section_device(skinrt_crowd* crowd, uint32_t section, uint32_t first, uint32_t count,
+                                                        uint32_t layout, const float* dev_attr, void* dev_dst);
+/* InstanceUniform records for instances [first, first + count) x the listed nodes, one kernel:
+ * record (k, n) at dev_dst + (k * node_count + n) * stride, stride >= 124 and a multiple of 4 (256 suits wgpu's
+ * dynamic uniform offsets); bytes 124..stride of a record are not written.  dev_nodes: DEVICE array
+ * [node_count] of flat node indices (indices >= the rig's node count write an all-zero record).  dev_dst 4-byte
+ * aligned.  Same bytes as skinrt_export_instance_uniform. */
+SKINRT_API int skinrt_export_instance_uniform_device(skinrt_crowd* crowd, uint32_t first, uint32_t count, const uint32_t* dev_nodes,
+                                                     uint32_t node_count, uint32_t stride, void* dev_dst);
 
 /* ---- load-time geometry ------------------------------------------------ */
 /* calculate_tangent (renderer-asset/src/tangent.rs:15-58) on the device: per-vertex sum of the unit

@@ -80,6 +80,11 @@ class Oracle:
         self.lib.orc_evaluate.restype = C.c_int
         self.lib.orc_evaluate.argtypes = [C.POINTER(RigDesc), C.POINTER(CrowdIn), C.POINTER(Out), C.c_uint32, C.c_uint32]
         self.lib.orc_find_key.restype = C.c_uint32
+        self.lib.orc_evaluate_sampled.restype = C.c_int
+        self.lib.orc_evaluate_sampled.argtypes = [C.POINTER(RigDesc), C.POINTER(CrowdIn), C.POINTER(Out), C.c_uint32, C.c_uint32,
+                                                  C.c_uint32, C.c_uint32]
+        self.lib.orc_palette_count.restype = C.c_uint32
+        self.lib.orc_palette_count.argtypes = [C.POINTER(RigDesc)]
 
     # --- unit functions (known-answer tests) ----------------------------------------------
     def _vec(self, a):
@@ -153,11 +158,44 @@ class Oracle:
             raise IndexError("vertex index out of range (reference: index panic)")
         return out
 
+    def instance_uniform(self, world16):
+        """InstanceUniform (uniform/transform.rs:8-14) of one world matrix: 31 values (mat4, 3 padded normal columns, padding)."""
+        m = self._vec(world16).reshape(16)
+        out = np.zeros(31, dtype=self.real)
+        self.lib.orc_instance_uniform(self._p(m), self._p(out))
+        return out
+
+    def rigid_vertex(self, iu31, p, n, t, normalize=0):
+        iu31, p, n, t = self._vec(iu31).reshape(31), self._vec(p), self._vec(n), self._vec(t)
+        op, on, ot = (np.zeros(3, dtype=self.real) for _ in range(3))
+        self.lib.orc_rigid_vertex(self._p(iu31), self._p(p), self._p(n), self._p(t), C.c_int(int(normalize)), self._p(op), self._p(on), self._p(ot))
+        return op, on, ot
+
+    def evaluate_mt(self, rig: RigData, tau, clip_id=None, morph_weights=None, root=None, *, threads=None, **kw) -> OracleResult:
+        """evaluate() with the instances split over host threads (ctypes releases the GIL inside orc_evaluate)."""
+        import os as _os
+        from concurrent.futures import ThreadPoolExecutor
+        n = int(np.asarray(tau).shape[0])
+        # a GPU box shows the whole machine's CPUs: its share is in OMP_NUM_THREADS
+        threads = threads or min(int(_os.environ.get("OMP_NUM_THREADS", "0")) or (_os.cpu_count() or 1), _os.cpu_count() or 1, 64)
+        threads = max(1, min(threads, n))
+        desc = kw.pop("desc", None) or rig.to_desc()
+        res = self.evaluate(rig, tau, clip_id, morph_weights, root, begin=0, end=0, desc=desc, **kw)  # allocates the outputs
+        cuts = [n * k // threads for k in range(threads + 1)]
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda k: self.evaluate(rig, tau, clip_id, morph_weights, root, begin=cuts[k], end=cuts[k + 1], desc=desc,
+                                                into=res, **kw), range(threads)))
+        return res
+
     # --- whole path --------------------------------------------------------------------------
     def evaluate(self, rig: RigData, tau, clip_id=None, morph_weights=None, root=None, *,
                  cubic_quirk=1, normalize_outputs=0, want=("world", "palette", "key_index", "position",
                                                            "normal", "tangent", "aabb"),
-                 begin=0, end=None, desc=None, into: Optional[OracleResult] = None) -> OracleResult:
+                 begin=0, end=None, desc=None, into: Optional[OracleResult] = None,
+                 vertex_step: int = 1, vertex_phase: int = 0) -> OracleResult:
+        """vertex_step > 1: position / normal / tangent hold only the vertices v of instance i with
+        v % vertex_step == (vertex_phase + i) % vertex_step, compacted to [I][ceil(V / vertex_step)][3] (row v // vertex_step);
+        no bounds (orc_evaluate_sampled)."""
         tau = np.ascontiguousarray(tau, dtype=np.float32)
         n_inst = tau.shape[0]
         end = n_inst if end is None else end
@@ -178,13 +216,15 @@ class Oracle:
         cin.cubic_quirk = int(cubic_quirk)
         cin.normalize_outputs = int(normalize_outputs)
         res = into if into is not None else OracleResult()
+        vrows = rig.vertex_count if vertex_step <= 1 else (rig.vertex_count + vertex_step - 1) // vertex_step
+        assert self.lib.orc_palette_count(C.byref(desc)) == rig.palette_count
         shapes = {
             "world": ((n_inst, rig.node_count, 16), self.real),
-            "palette": ((n_inst, rig.joint_count, 28), self.real),
+            "palette": ((n_inst, rig.palette_count, 28), self.real),
             "key_index": ((n_inst, rig.max_channels), np.uint32),
-            "position": ((n_inst, rig.vertex_count, 3), self.real),
-            "normal": ((n_inst, rig.vertex_count, 3), self.real),
-            "tangent": ((n_inst, rig.vertex_count, 3), self.real),
+            "position": ((n_inst, vrows, 3), self.real),
+            "normal": ((n_inst, vrows, 3), self.real),
+            "tangent": ((n_inst, vrows, 3), self.real),
             "aabb": ((n_inst, 2, 3), self.real),
         }
         out = Out()
@@ -193,7 +233,12 @@ class Oracle:
                 shp, dt = shapes[name]
                 setattr(res, name, np.zeros(shp, dtype=dt))
             setattr(out, name, getattr(res, name).ctypes.data)
-        rc = self.lib.orc_evaluate(C.byref(desc), C.byref(cin), C.byref(out), C.c_uint32(begin), C.c_uint32(end))
+        if vertex_step > 1:
+            assert "aabb" not in want, "sampled evaluation computes no bounds"
+            rc = self.lib.orc_evaluate_sampled(C.byref(desc), C.byref(cin), C.byref(out), C.c_uint32(begin), C.c_uint32(end),
+                                               C.c_uint32(vertex_step), C.c_uint32(vertex_phase))
+        else:
+            rc = self.lib.orc_evaluate(C.byref(desc), C.byref(cin), C.byref(out), C.c_uint32(begin), C.c_uint32(end))
         if rc != 0:
             raise RuntimeError(f"orc_evaluate failed: {rc}")
         del keep

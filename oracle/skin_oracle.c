@@ -429,19 +429,112 @@ static uint32_t max_channels(const skinrt_rig_desc* rig) {
     return m;
 }
 
-/* Evaluate instances [begin, end).  Output arrays are indexed by absolute instance. */
-ORC_API int orc_evaluate(const skinrt_rig_desc* rig, const orc_crowd_in* in, const orc_out* out,
-                         uint32_t begin, uint32_t end) {
-    const uint32_t N = rig->node_count, J = rig->joint_count, V = rig->vertex_count;
+/* ---- skins and sections (skinrt.h ABI 6): the short forms resolved exactly as the header states them ------------- */
+typedef struct orc_layout {
+    uint32_t skin_count, section_count, rigid_count, joints, palette; /* palette = joints + rigid_count */
+    skinrt_skin_desc* skins;
+    uint32_t* skin_first;            /* first palette entry of each skin */
+    skinrt_section_desc* sections;
+    uint32_t* section_entry;         /* skinned: its skin's first entry; un-skinned: the entry of its node */
+    uint32_t* rigid_node;            /* [rigid_count] */
+    int one_section;                 /* short form: weights channels are not matched by node */
+} orc_layout;
+
+static void layout_free(orc_layout* L) {
+    free(L->skins); free(L->skin_first); free(L->sections); free(L->section_entry); free(L->rigid_node);
+}
+
+static int layout_build(const skinrt_rig_desc* rig, orc_layout* L) {
+    memset(L, 0, sizeof *L);
+    L->skin_count = rig->skin_count ? rig->skin_count : (rig->joint_count ? 1u : 0u);
+    L->skins = (skinrt_skin_desc*)calloc(L->skin_count ? L->skin_count : 1, sizeof(skinrt_skin_desc));
+    L->skin_first = (uint32_t*)calloc(L->skin_count ? L->skin_count : 1, sizeof(uint32_t));
+    L->one_section = rig->section_count == 0;
+    L->section_count = rig->section_count ? rig->section_count : ((rig->vertex_count || rig->target_count) ? 1u : 0u);
+    L->sections = (skinrt_section_desc*)calloc(L->section_count ? L->section_count : 1, sizeof(skinrt_section_desc));
+    L->section_entry = (uint32_t*)calloc(L->section_count ? L->section_count : 1, sizeof(uint32_t));
+    L->rigid_node = (uint32_t*)calloc(L->section_count ? L->section_count : 1, sizeof(uint32_t));
+    if (!L->skins || !L->skin_first || !L->sections || !L->section_entry || !L->rigid_node) return SKINRT_E_NOMEM;
+    if (rig->skin_count) memcpy(L->skins, rig->skins, rig->skin_count * sizeof(skinrt_skin_desc));
+    else if (rig->joint_count) { L->skins[0].joint_count = rig->joint_count; L->skins[0].joint_node = rig->joint_node; L->skins[0].inverse_bind = rig->inverse_bind; }
+    for (uint32_t k = 0; k < L->skin_count; ++k) { L->skin_first[k] = L->joints; L->joints += L->skins[k].joint_count; }
+    if (rig->section_count) memcpy(L->sections, rig->sections, rig->section_count * sizeof(skinrt_section_desc));
+    else if (L->section_count) {
+        skinrt_section_desc one = {0u, L->skin_count ? 0 : -1, 0u, rig->vertex_count, 0u, rig->target_count};
+        L->sections[0] = one;
+    }
+    for (uint32_t k = 0; k < L->section_count; ++k) {
+        const skinrt_section_desc* sc = &L->sections[k];
+        if (sc->skin >= 0) { L->section_entry[k] = L->skin_first[sc->skin]; continue; }
+        if (!sc->vertex_count) continue;
+        uint32_t r = 0;
+        while (r < L->rigid_count && L->rigid_node[r] != sc->node) ++r;
+        if (r == L->rigid_count) L->rigid_node[L->rigid_count++] = sc->node;
+        L->section_entry[k] = L->joints + r;
+    }
+    L->palette = L->joints + L->rigid_count;
+    return SKINRT_OK;
+}
+
+/* Number of palette entries orc_evaluate writes per instance (orc_out.palette is [I][that][28]). */
+ORC_API uint32_t orc_palette_count(const skinrt_rig_desc* rig) {
+    orc_layout L;
+    uint32_t n = 0;
+    if (layout_build(rig, &L) == SKINRT_OK) n = L.palette;
+    layout_free(&L);
+    return n;
+}
+
+/* InstanceUniform — renderer/src/renderer/uniform/transform.rs:8-14, :36-42: transform.to_cols_array_2d(), then
+ * calculate_normal_transform (:27-34), then 12 bytes of padding.  out31: 16 + 12 + 3 values. */
+ORC_API void orc_instance_uniform(const real* world16, real* out31) {
+    memcpy(out31, world16, 16 * sizeof(real));
+    orc_normal_transform(world16, out31 + 16);
+    out31[28] = out31[29] = out31[30] = (real)0.0;
+}
+
+/* Un-skinned vertex — renderer/src/shader/shader.wgsl:143-152 (color_vs_main; texture_vs_main :167-176 is the same):
+ * instance.transform * vec4(position, 1), instance.normal * normal, instance.normal * tangent;
+ * mat*vec = ((c0*x + c1*y) + c2*z) + c3*w.  The outline variants normalize() (:198-199). */
+ORC_API void orc_rigid_vertex(const real* iu31, const real* p, const real* n, const real* t, int normalize, real* op, real* on, real* ot) {
+    const real* S = iu31;
+    const real* Nm = iu31 + 16;
+    for (int r = 0; r < 3; ++r) {
+        op[r] = ((S[0 + r] * p[0] + S[4 + r] * p[1]) + S[8 + r] * p[2]) + S[12 + r] * (real)1.0;
+        on[r] = (Nm[0 + r] * n[0] + Nm[4 + r] * n[1]) + Nm[8 + r] * n[2];
+        ot[r] = (Nm[0 + r] * t[0] + Nm[4 + r] * t[1]) + Nm[8 + r] * t[2];
+    }
+    if (normalize) {
+        real ln = vlen3(on), lt = vlen3(ot);
+        for (int r = 0; r < 3; ++r) { on[r] = on[r] / ln; ot[r] = ot[r] / lt; }
+    }
+}
+
+/* Evaluate instances [begin, end).  Output arrays are indexed by absolute instance.
+ * vertex_step > 1 (orc_evaluate_sampled): positions / normals / tangents are computed only for the vertices v of
+ * instance i with v % vertex_step == (vertex_phase + i) % vertex_step — the phase walks with the instance, so a crowd
+ * covers every vertex — and are written COMPACTED, row v / vertex_step of [I][ceil(V / vertex_step)][3]; bounds are
+ * not computed.  The full-size parity tests' way to meet every tile of every instance in bounded time and memory. */
+static int evaluate_impl(const skinrt_rig_desc* rig, const orc_crowd_in* in, const orc_out* out,
+                         uint32_t begin, uint32_t end, uint32_t vertex_step, uint32_t vertex_phase) {
+    const uint32_t N = rig->node_count, V = rig->vertex_count;
     const uint32_t M = rig->target_count, K = rig->set_count, Cmax = max_channels(rig);
     const uint32_t ts = rig->tangent_stride ? rig->tangent_stride : 3;
+    orc_layout L;
+    if (layout_build(rig, &L) != SKINRT_OK) { layout_free(&L); return SKINRT_E_NOMEM; }
+    const uint32_t J = L.palette;
     real* trs = (real*)malloc((size_t)N * 10 * sizeof(real));
     unsigned char* is_trs = (unsigned char*)malloc(N ? N : 1);
     real* world = (real*)malloc((size_t)(N ? N : 1) * 16 * sizeof(real));
     real* pal = (real*)malloc((size_t)(J ? J : 1) * 28 * sizeof(real));
     real* mw = (real*)malloc((size_t)(M ? M : 1) * sizeof(real));
     real* mw_anim = (real*)malloc((size_t)(M ? M : 1) * sizeof(real));
-    if (!trs || !is_trs || !world || !pal || !mw || !mw_anim) return SKINRT_E_NOMEM;
+    unsigned char* mw_have = (unsigned char*)malloc(M ? M : 1);
+    uint32_t* cur = (uint32_t*)malloc((M ? M : 1) * sizeof(uint32_t));
+    uint32_t* target_section = (uint32_t*)calloc(M ? M : 1, sizeof(uint32_t));
+    if (!trs || !is_trs || !world || !pal || !mw || !mw_anim || !mw_have || !cur || !target_section) return SKINRT_E_NOMEM;
+    for (uint32_t s = 0; s < L.section_count; ++s)
+        for (uint32_t m = 0; m < L.sections[s].target_count; ++m) target_section[L.sections[s].first_target + m] = s;
 
     for (uint32_t i = begin; i < end; ++i) {
         /* -- a6: local transform selection ------------------------------------------- */
@@ -452,7 +545,7 @@ ORC_API int orc_evaluate(const skinrt_rig_desc* rig, const orc_crowd_in* in, con
             for (int e = 0; e < 3; ++e) trs[n * 10 + 7 + e] = (real)rig->scale[n * 3 + e];
         }
         uint32_t clip = in->clip_id ? in->clip_id[i] : 0;
-        int have_anim_weights = 0;
+        memset(mw_have, 0, M ? M : 1);
         if (out->key_index)
             for (uint32_t c = 0; c < Cmax; ++c) out->key_index[(size_t)i * Cmax + c] = UINT32_MAX;
         if (clip != UINT32_MAX && clip < rig->clip_count) {
@@ -461,10 +554,16 @@ ORC_API int orc_evaluate(const skinrt_rig_desc* rig, const orc_crowd_in* in, con
             for (uint32_t c = 0; c < cl->channel_count; ++c) {
                 const skinrt_channel_desc* ch = &cl->channels[c];
                 uint32_t n = ch->target_node;
-                if (ch->path == SKINRT_PATH_WEIGHTS) { /* morph weights, not the node's transform */
-                    uint32_t kw = orc_sample_weights(ch, M, tau, (int)in->cubic_quirk, mw_anim);
+                if (ch->path == SKINRT_PATH_WEIGHTS) { /* morph weights of the mesh on that node, not the node's transform */
+                    uint32_t first = 0, width = M;
+                    if (!L.one_section) {
+                        width = 0;
+                        for (uint32_t s = 0; s < L.section_count; ++s)
+                            if (L.sections[s].node == n && L.sections[s].target_count) { first = L.sections[s].first_target; width = L.sections[s].target_count; break; }
+                    }
+                    uint32_t kw = orc_sample_weights(ch, width, tau, (int)in->cubic_quirk, mw_anim + first);
                     if (out->key_index) out->key_index[(size_t)i * Cmax + c] = kw;
-                    have_anim_weights = 1;
+                    memset(mw_have + first, 1, width);
                     continue;
                 }
                 if (!is_trs[n]) { /* Matrix node that is animated: decompose once (node.rs:76-82) */
@@ -495,62 +594,92 @@ ORC_API int orc_evaluate(const skinrt_rig_desc* rig, const orc_crowd_in* in, con
             } else memcpy(&world[(size_t)n * 16], local, sizeof local);
         }
         if (out->world) memcpy(out->world + (size_t)i * N * 16, world, (size_t)N * 16 * sizeof(real));
-        /* -- a8 + a9: joint matrices and SkinMatrix entries --------------------------- */
-        for (uint32_t j = 0; j < J; ++j) {
-            real* e = pal + (size_t)j * 28;
-            const real* wj = &world[(size_t)rig->joint_node[j] * 16];
-            if (rig->inverse_bind) {
-                real ibm[16];
-                for (int x = 0; x < 16; ++x) ibm[x] = (real)rig->inverse_bind[(size_t)j * 16 + x];
-                orc_mat4_mul(wj, ibm, e);
-            } else memcpy(e, wj, 16 * sizeof(real));
-            orc_normal_transform(e, e + 16);
+        /* -- a8 + a9: joint matrices and SkinMatrix entries, skin after skin (skin.rs:5-11) ----------- */
+        for (uint32_t s = 0; s < L.skin_count; ++s)
+            for (uint32_t q = 0; q < L.skins[s].joint_count; ++q) {
+                real* e = pal + (size_t)(L.skin_first[s] + q) * 28;
+                const real* wj = &world[(size_t)L.skins[s].joint_node[q] * 16];
+                if (L.skins[s].inverse_bind) {
+                    real ibm[16];
+                    for (int x = 0; x < 16; ++x) ibm[x] = (real)L.skins[s].inverse_bind[(size_t)q * 16 + x];
+                    orc_mat4_mul(wj, ibm, e);
+                } else memcpy(e, wj, 16 * sizeof(real));
+                orc_normal_transform(e, e + 16);
+            }
+        /* un-skinned sections: the InstanceUniform of their node, kept behind the joints (28 of its 31 values) */
+        for (uint32_t r = 0; r < L.rigid_count; ++r) {
+            real iu[31];
+            orc_instance_uniform(&world[(size_t)L.rigid_node[r] * 16], iu);
+            memcpy(pal + (size_t)(L.joints + r) * 28, iu, 28 * sizeof(real));
         }
         if (out->palette) memcpy(out->palette + (size_t)i * J * 28, pal, (size_t)J * 28 * sizeof(real));
         if (!out->position && !out->normal && !out->tangent && !out->aabb) continue;
-        /* -- a13: morph weights: node override, else mesh default, else 0 ------------- */
+        /* -- a13: morph weights: weights channel of the clip, else node override, else mesh default, else 0 -- */
         for (uint32_t m = 0; m < M; ++m)
-            mw[m] = have_anim_weights ? mw_anim[m]  /* the clip's weights channel overrides (skinrt.h) */
+            mw[m] = mw_have[m] ? mw_anim[m]  /* the clip's weights channel overrides (skinrt.h) */
                   : in->morph_weights ? (real)in->morph_weights[(size_t)i * M + m]
                                       : (rig->default_weights ? (real)rig->default_weights[m] : (real)0.0);
         real lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        /* cursors into compacted targets (indices strictly increasing) */
-        uint32_t* cur = (uint32_t*)calloc(M ? M : 1, sizeof(uint32_t));
-        if (!cur) return SKINRT_E_NOMEM;
-        for (uint32_t v = 0; v < V; ++v) {
-            real p[3], n[3], t[3];
-            for (int e = 0; e < 3; ++e) {
-                p[e] = (real)rig->position[v * 3 + e];
-                n[e] = (real)rig->normal[v * 3 + e];
-                t[e] = (real)rig->tangent[v * ts + e];
-            }
-            /* p = p0 + sum_m w_m * delta_m, target order; absent delta = zeros */
-            for (uint32_t m = 0; m < M; ++m) {
-                const skinrt_morph_target_desc* tg = &rig->targets[m];
-                uint32_t row;
-                if (tg->indices) {
-                    if (cur[m] < tg->count && tg->indices[cur[m]] == v) row = cur[m]++; else continue;
-                } else row = v;
+        /* cursors into compacted targets (indices strictly increasing, counted from the section's first vertex) */
+        memset(cur, 0, (M ? M : 1) * sizeof(uint32_t));
+        for (uint32_t s = 0; s < L.section_count; ++s) {
+            const skinrt_section_desc* sc = &L.sections[s];
+            for (uint32_t lv = 0; lv < sc->vertex_count; ++lv) {
+                const uint32_t v = sc->first_vertex + lv;
+                if (vertex_step > 1 && v % vertex_step != (vertex_phase + i) % vertex_step) continue;
+                real p[3], n[3], t[3];
                 for (int e = 0; e < 3; ++e) {
-                    if (tg->position) p[e] = p[e] + mw[m] * (real)tg->position[row * 3 + e];
-                    if (tg->normal) n[e] = n[e] + mw[m] * (real)tg->normal[row * 3 + e];
-                    if (tg->tangent) t[e] = t[e] + mw[m] * (real)tg->tangent[row * ts + e];
+                    p[e] = (real)rig->position[(size_t)v * 3 + e];
+                    n[e] = (real)rig->normal[(size_t)v * 3 + e];
+                    t[e] = (real)rig->tangent[(size_t)v * ts + e];
+                }
+                /* p = p0 + sum_m w_m * delta_m, the section's targets in order; absent delta = zeros */
+                for (uint32_t m = sc->first_target; m < sc->first_target + sc->target_count; ++m) {
+                    const skinrt_morph_target_desc* tg = &rig->targets[m];
+                    uint32_t row;
+                    if (tg->indices && vertex_step > 1) { /* sampled vertices: no cursor to carry, search the row */
+                        uint32_t a = 0, b = tg->count;
+                        while (a < b) { uint32_t mid = (a + b) >> 1; if (tg->indices[mid] < lv) a = mid + 1; else b = mid; }
+                        if (a < tg->count && tg->indices[a] == lv) row = a; else continue;
+                    } else if (tg->indices) {
+                        if (cur[m] < tg->count && tg->indices[cur[m]] == lv) row = cur[m]++; else continue;
+                    } else row = lv;
+                    for (int e = 0; e < 3; ++e) {
+                        if (tg->position) p[e] = p[e] + mw[m] * (real)tg->position[(size_t)row * 3 + e];
+                        if (tg->normal) n[e] = n[e] + mw[m] * (real)tg->normal[(size_t)row * 3 + e];
+                        if (tg->tangent) t[e] = t[e] + mw[m] * (real)tg->tangent[(size_t)row * ts + e];
+                    }
+                }
+                real op[3], on[3], ot[3];
+                if (sc->skin >= 0)
+                    orc_skin_vertex(pal + (size_t)L.section_entry[s] * 28, K, rig->joints, rig->weights, v, p, n, t, (int)in->normalize_outputs, op, on, ot);
+                else {
+                    real iu[31];
+                    orc_instance_uniform(&world[(size_t)sc->node * 16], iu);
+                    orc_rigid_vertex(iu, p, n, t, (int)in->normalize_outputs, op, on, ot);
+                }
+                size_t o = vertex_step > 1 ? ((size_t)i * ((V + vertex_step - 1) / vertex_step) + v / vertex_step) * 3 : ((size_t)i * V + v) * 3;
+                for (int e = 0; e < 3; ++e) {
+                    if (out->position) out->position[o + e] = op[e];
+                    if (out->normal) out->normal[o + e] = on[e];
+                    if (out->tangent) out->tangent[o + e] = ot[e];
+                    if (op[e] < lo[e]) lo[e] = op[e];
+                    if (op[e] > hi[e]) hi[e] = op[e];
                 }
             }
-            real op[3], on[3], ot[3];
-            orc_skin_vertex(pal, K, rig->joints, rig->weights, v, p, n, t, (int)in->normalize_outputs, op, on, ot);
-            size_t o = ((size_t)i * V + v) * 3;
-            for (int e = 0; e < 3; ++e) {
-                if (out->position) out->position[o + e] = op[e];
-                if (out->normal) out->normal[o + e] = on[e];
-                if (out->tangent) out->tangent[o + e] = ot[e];
-                if (op[e] < lo[e]) lo[e] = op[e];
-                if (op[e] > hi[e]) hi[e] = op[e];
-            }
         }
-        free(cur);
-        if (out->aabb) for (int e = 0; e < 3; ++e) { out->aabb[(size_t)i * 6 + e] = lo[e]; out->aabb[(size_t)i * 6 + 3 + e] = hi[e]; }
+        if (out->aabb && vertex_step <= 1) for (int e = 0; e < 3; ++e) { out->aabb[(size_t)i * 6 + e] = lo[e]; out->aabb[(size_t)i * 6 + 3 + e] = hi[e]; }
     }
-    free(trs); free(is_trs); free(world); free(pal); free(mw); free(mw_anim);
+    free(trs); free(is_trs); free(world); free(pal); free(mw); free(mw_anim); free(mw_have); free(cur); free(target_section);
+    layout_free(&L);
     return SKINRT_OK;
+}
+
+ORC_API int orc_evaluate(const skinrt_rig_desc* rig, const orc_crowd_in* in, const orc_out* out, uint32_t begin, uint32_t end) {
+    return evaluate_impl(rig, in, out, begin, end, 1, 0);
+}
+
+ORC_API int orc_evaluate_sampled(const skinrt_rig_desc* rig, const orc_crowd_in* in, const orc_out* out, uint32_t begin, uint32_t end,
+                                 uint32_t vertex_step, uint32_t vertex_phase) {
+    return evaluate_impl(rig, in, out, begin, end, vertex_step, vertex_phase);
 }

@@ -38,6 +38,7 @@ class Config(C.Structure):
         ("pose_path", C.c_uint32),
         ("skin_path", C.c_uint32),
         ("output_placement", C.c_uint32),
+        ("allow_experimental_build", C.c_uint32),
     ]
 
 
@@ -79,6 +80,25 @@ class MorphTargetDesc(C.Structure):
     ]
 
 
+class SkinDesc(C.Structure):
+    _fields_ = [("joint_count", C.c_uint32), ("joint_node", _u32p), ("inverse_bind", _f32p)]
+
+
+class SectionDesc(C.Structure):
+    _fields_ = [("node", C.c_uint32), ("skin", C.c_int32), ("first_vertex", C.c_uint32), ("vertex_count", C.c_uint32),
+                ("first_target", C.c_uint32), ("target_count", C.c_uint32)]
+
+
+class SkinLayout(C.Structure):
+    _fields_ = [("first_palette_entry", C.c_uint32), ("joint_count", C.c_uint32)]
+
+
+class SectionLayout(C.Structure):
+    _fields_ = [("node", C.c_uint32), ("skin", C.c_int32), ("first_vertex", C.c_uint32), ("vertex_count", C.c_uint32),
+                ("first_target", C.c_uint32), ("target_count", C.c_uint32), ("first_palette_entry", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
 class RigDesc(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -105,6 +125,10 @@ class RigDesc(C.Structure):
         ("target_count", C.c_uint32),
         ("targets", C.POINTER(MorphTargetDesc)),
         ("default_weights", _f32p),
+        ("skin_count", C.c_uint32),
+        ("skins", C.POINTER(SkinDesc)),
+        ("section_count", C.c_uint32),
+        ("sections", C.POINTER(SectionDesc)),
     ]
 
 
@@ -117,6 +141,7 @@ class RigInfo(C.Structure):
         ("morph_entries", C.c_uint64), ("device_bytes", C.c_uint64),
         ("exact_arithmetic", C.c_uint32), ("bind_extent", C.c_float),
         ("weight_channel_clips", C.c_uint32), ("skip_weight_sets", C.c_uint32),
+        ("skin_count", C.c_uint32), ("section_count", C.c_uint32), ("palette_count", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -155,6 +180,25 @@ class MorphTarget:
 
 
 @dataclass
+class Skin:
+    """SkinAsset (renderer-asset/src/skin.rs:5-11): joints as flat node indices, inverse bind matrices or None."""
+    joint_node: np.ndarray                      # [J] u32
+    inverse_bind: Optional[np.ndarray] = None   # [J][16]
+
+
+@dataclass
+class Section:
+    """A NodeAsset with a mesh (renderer-asset/src/node.rs:89-99): its vertices and morph targets in the rig's arrays,
+    its skin (index into RigData.skins) or -1 for an un-skinned mesh placed by the node's world matrix."""
+    node: int
+    skin: int
+    first_vertex: int
+    vertex_count: int
+    first_target: int = 0
+    target_count: int = 0
+
+
+@dataclass
 class RigData:
     parent: np.ndarray                     # [N] i32
     translation: np.ndarray                # [N][3]
@@ -173,6 +217,8 @@ class RigData:
     targets: List[MorphTarget] = field(default_factory=list)
     default_weights: Optional[np.ndarray] = None
     name: str = "rig"
+    skins: Optional[List[Skin]] = None          # several skins on one node tree (then joint_node / inverse_bind above are unused)
+    sections: Optional[List[Section]] = None    # mesh instances; None = one section: all vertices, all targets, skin 0
 
     def __post_init__(self):
         self.parent = _arr(self.parent, np.int32)
@@ -203,12 +249,46 @@ class RigData:
             for ch in clip:
                 ch.times = _arr(ch.times, np.float32)
                 ch.values = _arr(ch.values, np.float32)
+        for sk in self.skins or []:
+            sk.joint_node = _arr(sk.joint_node, np.uint32)
+            sk.inverse_bind = _arr(sk.inverse_bind, np.float32, (sk.joint_node.shape[0], 16)) if sk.inverse_bind is not None else None
 
     # sizes ------------------------------------------------------------------------------
     @property
     def node_count(self): return int(self.parent.shape[0])
     @property
-    def joint_count(self): return int(self.joint_node.shape[0])
+    def joint_count(self):
+        """joints of all skins together"""
+        if self.skins is not None:
+            return sum(int(sk.joint_node.shape[0]) for sk in self.skins)
+        return int(self.joint_node.shape[0])
+
+    def skin_list(self) -> List[Skin]:
+        """the skins, whichever form the rig uses (short form: one skin, or none without joints)"""
+        if self.skins is not None:
+            return self.skins
+        return [Skin(self.joint_node, self.inverse_bind)] if self.joint_node.shape[0] else []
+
+    def section_list(self) -> List[Section]:
+        if self.sections is not None:
+            return self.sections
+        if not self.vertex_count and not self.target_count:
+            return []
+        return [Section(0, 0 if self.skin_list() else -1, 0, self.vertex_count, 0, self.target_count)]
+
+    def rigid_nodes(self) -> List[int]:
+        """distinct nodes of un-skinned sections with vertices, in section order: one palette entry each after the skins' joints"""
+        out: List[int] = []
+        for sc in self.section_list():
+            if sc.skin < 0 and sc.vertex_count and sc.node not in out:
+                out.append(sc.node)
+        return out
+
+    @property
+    def palette_count(self): return self.joint_count + len(self.rigid_nodes())
+
+    def skin_first(self, skin: int) -> int:
+        return sum(int(sk.joint_node.shape[0]) for sk in self.skin_list()[:skin])
     @property
     def vertex_count(self): return int(self.position.shape[0])
     @property
@@ -223,6 +303,12 @@ class RigData:
     def clip_length(self, clip: int) -> float:
         """max over channels of AnimationChannelAsset.length (loader/gltf/mod.rs:1243-1247)."""
         return max([float(ch.times.max()) for ch in self.clips[clip]], default=0.0)
+
+    def _target_section(self, m: int) -> Section:
+        for sc in self.section_list():
+            if sc.first_target <= m < sc.first_target + sc.target_count:
+                return sc
+        raise IndexError(f"morph target {m} belongs to no section")
 
     def to_desc(self) -> "RigDesc":
         d = RigDesc()
@@ -268,7 +354,7 @@ class RigData:
         d.target_count = len(self.targets)
         t_arr = (MorphTargetDesc * max(1, len(self.targets)))()
         for k, t in enumerate(self.targets):
-            cnt = self.vertex_count if t.indices is None else int(t.indices.shape[0])
+            cnt = self._target_section(k).vertex_count if t.indices is None else int(t.indices.shape[0])
             t_arr[k].count = cnt
             t_arr[k].indices = _ptr(t.indices, _u32p)
             t_arr[k].position = _ptr(t.position, _f32p)
@@ -277,5 +363,26 @@ class RigData:
         keep.append(t_arr)
         d.targets = C.cast(t_arr, C.POINTER(MorphTargetDesc))
         d.default_weights = _ptr(self.default_weights, _f32p)
+        if self.skins is not None:
+            sk_arr = (SkinDesc * max(1, len(self.skins)))()
+            for k, sk in enumerate(self.skins):
+                sk_arr[k].joint_count = sk.joint_node.shape[0]
+                sk_arr[k].joint_node = _ptr(sk.joint_node, _u32p)
+                sk_arr[k].inverse_bind = _ptr(sk.inverse_bind, _f32p)
+            keep.append(sk_arr)
+            d.skin_count = len(self.skins)
+            d.skins = C.cast(sk_arr, C.POINTER(SkinDesc))
+            d.joint_count = 0
+            d.joint_node = C.cast(None, _u32p)
+            d.inverse_bind = C.cast(None, _f32p)
+        if self.sections is not None:
+            sc_arr = (SectionDesc * max(1, len(self.sections)))()
+            for k, sc in enumerate(self.sections):
+                sc_arr[k].node, sc_arr[k].skin = sc.node, sc.skin
+                sc_arr[k].first_vertex, sc_arr[k].vertex_count = sc.first_vertex, sc.vertex_count
+                sc_arr[k].first_target, sc_arr[k].target_count = sc.first_target, sc.target_count
+            keep.append(sc_arr)
+            d.section_count = len(self.sections)
+            d.sections = C.cast(sc_arr, C.POINTER(SectionDesc))
         d._keep = (keep, self)  # keep python owners alive as long as the struct lives
         return d

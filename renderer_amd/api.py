@@ -19,7 +19,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 from . import abi
-from .abi import Config, PlacementInfo, RigData, RigDesc, RigInfo
+from .abi import Config, PlacementInfo, RigData, RigDesc, RigInfo, SectionLayout, SkinLayout
 
 _LIB_PATH = os.environ.get("SKINRT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libskinrt.so")
 _lib = None
@@ -34,7 +34,10 @@ EXPORTS = [
     "skinrt_get_palette", "skinrt_get_world", "skinrt_get_keyframe_index", "skinrt_download",
     "skinrt_export_skin_uniform", "skinrt_export_interleaved", "skinrt_calculate_tangent",
     "skinrt_calculate_tangent_noalloc", "skinrt_export_skin_uniform_device", "skinrt_export_interleaved_device",
-    "skinrt_shard_range",
+    "skinrt_shard_range", "skinrt_build_flags", "skinrt_rig_skin_layout", "skinrt_rig_section_layout",
+    "skinrt_set_clocks_async", "skinrt_advance_clocks", "skinrt_get_clocks",
+    "skinrt_export_skin_uniform_of", "skinrt_export_interleaved_section", "skinrt_export_instance_uniform",
+    "skinrt_export_skin_uniform_of_device", "skinrt_export_interleaved_section_device", "skinrt_export_instance_uniform_device",
     "skinrt_node_create", "skinrt_node_destroy", "skinrt_node_shard_count", "skinrt_node_get_shard", "skinrt_node_set_clocks",
     "skinrt_node_set_morph_weights", "skinrt_node_set_root_transforms", "skinrt_node_evaluate", "skinrt_node_synchronize",
     "skinrt_node_download_aabbs",
@@ -63,6 +66,8 @@ def load_library() -> C.CDLL:
     vp = C.c_void_p
     lib.skinrt_abi_version.restype = C.c_int
     lib.skinrt_last_error.restype = C.c_char_p
+    lib.skinrt_build_flags.restype = C.c_uint32
+    lib.skinrt_build_flags.argtypes = []
     sigs = {
         "skinrt_init": [C.POINTER(Config), C.POINTER(vp)],
         "skinrt_destroy_ctx": [vp],
@@ -85,6 +90,16 @@ def load_library() -> C.CDLL:
         "skinrt_export_interleaved": [vp, C.c_uint32, C.c_uint32, vp, vp],
         "skinrt_export_skin_uniform_device": [vp, C.c_uint32, C.c_uint32, vp],
         "skinrt_export_interleaved_device": [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp],
+        "skinrt_rig_skin_layout": [vp, C.c_uint32, C.POINTER(SkinLayout)],
+        "skinrt_rig_section_layout": [vp, C.c_uint32, C.POINTER(SectionLayout)],
+        "skinrt_set_clocks_async": [vp, vp, vp],
+        "skinrt_advance_clocks": [vp, C.c_float, vp],
+        "skinrt_export_skin_uniform_of": [vp, C.c_uint32, C.c_uint32, vp],
+        "skinrt_export_interleaved_section": [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp],
+        "skinrt_export_instance_uniform": [vp, C.c_uint32, C.c_uint32, vp],
+        "skinrt_export_skin_uniform_of_device": [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp],
+        "skinrt_export_interleaved_section_device": [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp],
+        "skinrt_export_instance_uniform_device": [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp],
         "skinrt_shard_range": [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
         "skinrt_calculate_tangent": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(C.c_float)],
         "skinrt_calculate_tangent_noalloc": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp],
@@ -99,7 +114,7 @@ def load_library() -> C.CDLL:
         "skinrt_node_synchronize": [vp],
         "skinrt_node_download_aabbs": [vp, vp],
     }
-    for g in ("positions", "normals", "tangents", "aabbs", "palette", "world", "keyframe_index"):
+    for g in ("positions", "normals", "tangents", "aabbs", "palette", "world", "keyframe_index", "clocks"):
         sigs[f"skinrt_get_{g}"] = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -115,7 +130,8 @@ def _check(rc: int):
 
 
 def make_config(device: int = 0, cubic_quirk: int = 1, normalize_outputs: int = 0, reference_limits: int = 0,
-                exact_arithmetic: int = 0, pose_path: int = 0, skin_path: int = 0, output_placement: int = 0) -> Config:
+                exact_arithmetic: int = 0, pose_path: int = 0, skin_path: int = 0, output_placement: int = 0,
+                allow_experimental_build: Optional[int] = None) -> Config:
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.device = device
@@ -126,6 +142,10 @@ def make_config(device: int = 0, cubic_quirk: int = 1, normalize_outputs: int = 
     cfg.pose_path = pose_path
     cfg.skin_path = skin_path
     cfg.output_placement = output_placement
+    # measurement builds (SKINRT_LIB pointing at a variant library) are refused by skinrt_init unless asked for
+    if allow_experimental_build is None:
+        allow_experimental_build = 1 if os.environ.get("SKINRT_ALLOW_EXPERIMENTAL") == "1" else 0
+    cfg.allow_experimental_build = allow_experimental_build
     return cfg
 
 
@@ -211,6 +231,16 @@ class Rig:
         _check(self.ctx.lib.skinrt_get_rig_info(self.handle, C.byref(info)))
         return info
 
+    def skin_layout(self, skin: int) -> SkinLayout:
+        out = SkinLayout()
+        _check(self.ctx.lib.skinrt_rig_skin_layout(self.handle, skin, C.byref(out)))
+        return out
+
+    def section_layout(self, section: int) -> SectionLayout:
+        out = SectionLayout()
+        _check(self.ctx.lib.skinrt_rig_section_layout(self.handle, section, C.byref(out)))
+        return out
+
     def close(self):
         if self.handle:
             self.ctx.lib.skinrt_destroy_rig(self.handle)
@@ -252,6 +282,17 @@ class Crowd:
             assert clip_id.shape == (self.instances,)
             cp = clip_id.ctypes.data_as(C.c_void_p)
         _check(self.ctx.lib.skinrt_set_clocks(self.handle, tau.ctypes.data_as(C.c_void_p), cp))
+
+    def set_clocks_async(self, tau_ptr: int, clip_ptr: int = 0):
+        """skinrt_set_clocks_async: device (or GPU-visible host) addresses; stream-ordered, does not block."""
+        _check(self.ctx.lib.skinrt_set_clocks_async(self.handle, C.c_void_p(tau_ptr), C.c_void_p(clip_ptr) if clip_ptr else None))
+
+    def advance_clocks(self, dt: float, rate_ptr: int = 0):
+        """skinrt_advance_clocks: tau = fmodf(tau + dt * rate, clip_length) on the device; rate_ptr: device [I] f32 or 0."""
+        _check(self.ctx.lib.skinrt_advance_clocks(self.handle, C.c_float(dt), C.c_void_p(rate_ptr) if rate_ptr else None))
+
+    def clocks(self) -> np.ndarray:
+        return self._fetch("clocks", np.float32, (self.instances,))
 
     def set_morph_weights(self, weights):
         wp = None
@@ -315,7 +356,7 @@ class Crowd:
     def palette(self, first=0, count=None):
         """[count][J][24]: 3 rows x 4 of the joint matrix, then 3 rows x 4 of the normal matrix (4th of each row 0).  The
         device buffer (skinrt_get_palette) keeps the nine normal entries packed; they are spread to padded rows here."""
-        dev = self._fetch("palette", np.float32, (self.instances, self.rig.data.joint_count, 24), first, count)
+        dev = self._fetch("palette", np.float32, (self.instances, self.rig.data.palette_count, 24), first, count)
         out = np.zeros_like(dev)
         out[..., :12] = dev[..., :12]
         for r in range(3):
@@ -344,6 +385,39 @@ class Crowd:
             ap = attr.ctypes.data_as(C.c_void_p)
         _check(self.ctx.lib.skinrt_export_interleaved(self.handle, instance, layout, ap, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def skin_uniform_of(self, skin: int, instance: int) -> np.ndarray:
+        """128 x SkinMatrix of one skin of a rig with several."""
+        out = np.empty((128, 28), dtype=np.float32)
+        _check(self.ctx.lib.skinrt_export_skin_uniform_of(self.handle, skin, instance, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def interleaved_section(self, section: int, instance: int, layout: int, attr=None) -> np.ndarray:
+        stride = 76 if layout == abi.LAYOUT_COLOR_SKIN else 68
+        out = np.empty(self.rig.section_layout(section).vertex_count * stride, dtype=np.uint8)
+        ap = None
+        if attr is not None:
+            attr = np.ascontiguousarray(attr, dtype=np.float32)
+            ap = attr.ctypes.data_as(C.c_void_p)
+        _check(self.ctx.lib.skinrt_export_interleaved_section(self.handle, section, instance, layout, ap, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def instance_uniform(self, instance: int, node: int) -> np.ndarray:
+        """InstanceUniform (124 bytes = 31 f32: mat4, 3 padded normal columns, 12 bytes of padding) of one node."""
+        out = np.empty(31, dtype=np.float32)
+        _check(self.ctx.lib.skinrt_export_instance_uniform(self.handle, instance, node, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def skin_uniform_of_device(self, skin: int, first: int, count: int, dev_dst: int):
+        _check(self.ctx.lib.skinrt_export_skin_uniform_of_device(self.handle, skin, first, count, C.c_void_p(dev_dst)))
+
+    def interleaved_section_device(self, section: int, first: int, count: int, layout: int, dev_attr: int, dev_dst: int):
+        _check(self.ctx.lib.skinrt_export_interleaved_section_device(self.handle, section, first, count, layout,
+                                                                     C.c_void_p(dev_attr) if dev_attr else None, C.c_void_p(dev_dst)))
+
+    def instance_uniform_device(self, first: int, count: int, dev_nodes: int, node_count: int, stride: int, dev_dst: int):
+        _check(self.ctx.lib.skinrt_export_instance_uniform_device(self.handle, first, count, C.c_void_p(dev_nodes), node_count, stride,
+                                                                  C.c_void_p(dev_dst)))
 
     def skin_uniform_device(self, first: int, count: int, dev_dst: int):
         """[count][128] SkinMatrix written by one kernel into device memory at `dev_dst` (asynchronous)."""

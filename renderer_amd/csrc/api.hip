@@ -52,8 +52,38 @@ struct DevBuf {
 
 }  // namespace
 
+// Scheduling knobs for measurements, read from the environment ONCE per skinrt_init (never per frame) and documented
+// in include/skinrt.h; none of them changes a result.
+struct EnvKnobs {
+    int fix_stream = 1;          // SKINRT_FIX_STREAM=0: the skin stage's kernels one after the other
+    int fix_prio = 1;            // SKINRT_FIX_PRIO: -1 urgent, 0 default, 1 least urgent side stream
+    uint32_t fix_order = 0;      // SKINRT_FIX_ORDER=1: enqueue k_skin2 before k_skin_fix
+    uint32_t fix_blocks = 32768; // SKINRT_FIX_BLOCKS: about this many k_skin_fix blocks
+    int pose_pre = 1;            // SKINRT_POSE_PRE=0: sample channels inside the pose kernels (no local_t scratch)
+    int tile_chunks = 0;         // SKINRT_TILE_CHUNKS: 1, 2, 4 or 8 tile chunks (0: chosen per rig)
+    int range2 = 0;              // SKINRT_RANGE2: instances per k_skin2 block (0: chosen per crowd)
+    int tile_run = 0;            // SKINRT_TILE_RUN: tiles per run dealt to an XCD (0: chosen per crowd)
+    int skip_sets = -1;          // SKINRT_SKIP_SETS: force the kernels that stop a wave after its last used weight set on / off
+    static int num(const char* name, int dflt) {
+        const char* v = std::getenv(name);
+        return v ? std::atoi(v) : dflt;
+    }
+    void read() {
+        fix_stream = num("SKINRT_FIX_STREAM", 1);
+        fix_prio = num("SKINRT_FIX_PRIO", 1);
+        fix_order = (uint32_t)std::max(0, num("SKINRT_FIX_ORDER", 0));
+        fix_blocks = (uint32_t)std::max(1, num("SKINRT_FIX_BLOCKS", 32768));
+        pose_pre = num("SKINRT_POSE_PRE", 1);
+        tile_chunks = num("SKINRT_TILE_CHUNKS", 0);
+        range2 = num("SKINRT_RANGE2", 0);
+        tile_run = num("SKINRT_TILE_RUN", 0);
+        skip_sets = num("SKINRT_SKIP_SETS", -1);
+    }
+};
+
 struct skinrt_ctx {
     skinrt_config cfg{};
+    EnvKnobs env;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;  // k_skin_fix next to k_skin2 (launch_skin)
 };
@@ -75,6 +105,9 @@ struct skinrt_crowd {
     uint32_t I = 0;
     DevBuf tau, clip, mw, mw_eff, local_t, root, world, palette, keyidx, pos, nrm, tan, aabb_part, aabb, fix, amask;
     bool has_root = false;
+    // rigs with weights channels: the host set morph weights / clocks / clips since mw_eff was last sampled, so a skin
+    // stage without a pose stage in front of it must refresh mw_eff first
+    bool mw_stale = true;
     SkinPlan plan{};
     PosePath pose_path = kPoseWave;
     skinrt_placement_info place{};
@@ -119,7 +152,7 @@ uint32_t ceil_log2(uint32_t x) {
     return s;
 }
 
-SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
+SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg, const EnvKnobs& env) {
     SkinPlan p{};
     p.jt_shift = ceil_log2(std::max<uint32_t>(1, r.max_tile_joints));
     const uint32_t JTP = 1u << p.jt_shift;
@@ -153,10 +186,8 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
         const uint32_t per = (T + tcs - 1) / tcs;
         if ((uint64_t)per * tcs * 100 <= (uint64_t)T * 104) { p.tile_chunks = tcs; break; }
     }
-    if (const char* ev = getenv("SKINRT_TILE_CHUNKS")) {  // experiments: 1, 2, 4 or 8 tile chunks (the other XCDs split the instance ranges)
-        const int v = atoi(ev);
-        if (v == 1 || v == 2 || v == 4 || v == 8) p.tile_chunks = (uint32_t)v;
-    }
+    if (env.tile_chunks == 1 || env.tile_chunks == 2 || env.tile_chunks == 4 || env.tile_chunks == 8)  // (the other XCDs split the instance ranges)
+        p.tile_chunks = (uint32_t)env.tile_chunks;
     p.tiles_per_chunk = (T + p.tile_chunks - 1) / p.tile_chunks;
     const uint32_t rcs = 8 / p.tile_chunks;
     p.ranges_per_chunk = (std::max<uint32_t>(1, p.ranges) + rcs - 1) / rcs;
@@ -179,14 +210,14 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg) {
         if (p.lds_bytes2 > 64 * 1024) p.v2 = 0;
         uint64_t r2 = ((uint64_t)I * std::max<uint32_t>(1, r.T) + want_blocks - 1) / want_blocks;
         p.range2 = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(r2, 1), kSkin2Range);
-        if (const char* ev = getenv("SKINRT_RANGE2")) p.range2 = std::min<uint32_t>(kSkin2Range, std::max(1, atoi(ev)));  // experiments
+        if (env.range2 > 0) p.range2 = std::min<uint32_t>(kSkin2Range, (uint32_t)env.range2);
         p.ranges2 = I ? (I + p.range2 - 1) / p.range2 : 0;
         p.ranges_per_chunk2 = (std::max<uint32_t>(1, p.ranges2) + rcs - 1) / rcs;
         // a block range's palettes fit an XCD's L2 twice over: interleave fully; else runs of 16 tiles (4096 vertices), which
         // keep most of the joint sharing between neighbouring tiles (C5: as fast as one contiguous chunk) and still spread
         // a mesh's busy regions over the XCDs
         p.run2 = (uint64_t)p.range2 * r.J * 96 <= (2u << 20) ? 1 : std::min<uint32_t>(16, p.tiles_per_chunk);
-        if (const char* ev = getenv("SKINRT_TILE_RUN")) p.run2 = std::min<uint32_t>(p.tiles_per_chunk, std::max(1, atoi(ev)));
+        if (env.tile_run > 0) p.run2 = std::min<uint32_t>(p.tiles_per_chunk, (uint32_t)env.tile_run);
         p.tiles_per_chunk2 = (p.tiles_per_chunk + p.run2 - 1) / p.run2 * p.run2;
     }
     p.exact = r.exact;  // skinrt_config.exact_arithmetic resolved per rig at compile time
@@ -221,6 +252,14 @@ extern "C" {
 
 int skinrt_abi_version(void) { return SKINRT_ABI_VERSION; }
 
+uint32_t skinrt_build_flags(void) {
+    uint32_t f = skin_build_flags();
+#ifdef SKINRT_STAMPS
+    f |= SKINRT_BUILD_STAMPS;
+#endif
+    return f;
+}
+
 const char* skinrt_last_error(void) { return g_err.c_str(); }
 
 int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx) {
@@ -230,6 +269,9 @@ int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx) {
     if (config->skin_path > 1) return fail(SKINRT_E_INVALID, "skinrt_config.skin_path must be 0 or 1");
     if (config->exact_arithmetic > 2) return fail(SKINRT_E_INVALID, "skinrt_config.exact_arithmetic must be 0, 1 or 2");
     if (config->output_placement > 1) return fail(SKINRT_E_INVALID, "skinrt_config.output_placement must be 0 or 1");
+    if (skinrt_build_flags() != 0 && !config->allow_experimental_build)
+        return fail(SKINRT_E_INVALID, "this libskinrt.so is a measurement build (skinrt_build_flags() = " + std::to_string(skinrt_build_flags()) +
+                                          "): its results may be wrong by design; set skinrt_config.allow_experimental_build to use it");
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (config->device < 0 || config->device >= count) return fail(SKINRT_E_DEVICE, "no such HIP device");
@@ -240,18 +282,17 @@ int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx) {
     skinrt_ctx* ctx = new (std::nothrow) skinrt_ctx;
     if (!ctx) return fail(SKINRT_E_NOMEM, "out of host memory");
     ctx->cfg = *config;
+    ctx->env.read();
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
         return fail(SKINRT_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     {
-        const char* ev = std::getenv("SKINRT_FIX_STREAM");  // 0: the skin stage's kernels one after the other (measurement)
-        if (!ev || std::atoi(ev) != 0) {
+        if (ctx->env.fix_stream != 0) {
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent (largest number)
-            const char* pv = std::getenv("SKINRT_FIX_PRIO");
-            const int want = pv ? std::atoi(pv) : 1;  // -1 urgent, 0 default, 1 least urgent (default: it only fills what k_skin2 leaves free)
+            const int want = ctx->env.fix_prio;  // -1 urgent, 0 default, 1 least urgent (default: it only fills what k_skin2 leaves free)
             e = hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, want < 0 ? hi : (want > 0 ? lo : (lo + hi) / 2));
             if (e != hipSuccess) {
                 (void)hipStreamDestroy(ctx->stream);
@@ -320,11 +361,11 @@ int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig**
     d.levels = h.levels; d.T = h.T;
     d.weight_channel_clips = h.weight_channel_clips;
     d.skip_sets = h.skip_sets ? 1u : 0u;
-    if (const char* ev = getenv("SKINRT_SKIP_SETS")) d.skip_sets = (h.K == 2 && atoi(ev) != 0) ? 1u : 0u;  // experiments (tools/exp_skip_sets.py)
+    if (ctx->env.skip_sets >= 0) d.skip_sets = (h.K == 2 && ctx->env.skip_sets != 0) ? 1u : 0u;  // tools/exp_skip_sets.py
     const float* defw = nullptr;
 #define UP(field) if ((rc = upload(r, h.field, &d.field)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
     UP(parent) UP(rest_trs) UP(rest_mat) UP(node_matrix) UP(level_start) UP(level_nodes) UP(node_chan)
-    UP(chans) UP(clip_chan_count) UP(clip_weights_chan) UP(times) UP(values) UP(joint_node) UP(ibm) UP(base) UP(wts) UP(lidx)
+    UP(chans) UP(clip_chan_count) UP(weight_src) UP(clip_length) UP(times) UP(values) UP(joint_node) UP(ibm) UP(base) UP(wts) UP(lidx)
     UP(tile_joint_start) UP(tile_joints) UP(tile_lds) UP(tile_pair_start) UP(pairs) UP(mblock)
 #undef UP
     if ((rc = upload(r, h.default_weights, &defw)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
@@ -402,7 +443,7 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
     }
     // sampled local matrices [N][I][12] of the lane-per-instance channel sampling (k_sample_nodes); allocated after the
     // output arrays so that their steering sees the same free memory with and without it
-    if (h.clips && !(std::getenv("SKINRT_POSE_PRE") && std::atoi(std::getenv("SKINRT_POSE_PRE")) == 0)) {
+    if (h.clips && ctx->env.pose_pre != 0) {
         if (c->local_t.alloc(I * h.N * 48) != hipSuccess) {
             (void)hipGetLastError();
             skinrt_destroy_crowd(c);
@@ -426,7 +467,7 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
         skinrt_destroy_crowd(c);
         return fail(SKINRT_E_DEVICE, std::string("crowd initialisation: ") + hipGetErrorString(e));
     }
-    c->plan = plan_skin(h, instances, ctx->cfg);
+    c->plan = plan_skin(h, instances, ctx->cfg, ctx->env);
     // the loader-wave kernel's LDS need grows with the longest pair list of a tile: refuse here, with a
     // reason, what skinrt_evaluate could only report as a failed launch
     if ((c->plan.kinds & 3u) || !c->plan.v2) {
@@ -468,6 +509,27 @@ int skinrt_set_clocks(skinrt_crowd* c, const float* tau, const uint32_t* clip_id
     if (clip_id) HIP_TRY(hipMemcpyAsync(c->clip.p, clip_id, c->clip.bytes, hipMemcpyHostToDevice, c->ctx->stream));
     else HIP_TRY(hipMemsetAsync(c->clip.p, 0, c->clip.bytes, c->ctx->stream));
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));  // host buffers are borrowed for the call only
+    c->mw_stale = true;
+    return SKINRT_OK;
+}
+
+int skinrt_set_clocks_async(skinrt_crowd* c, const float* tau, const uint32_t* clip_id) {
+    if (int rc = check_crowd(c)) return rc;
+    if (!tau) return fail(SKINRT_E_INVALID, "tau is NULL");
+    HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+    // hipMemcpyDefault: device memory or GPU-visible host memory; stream-ordered, the host does not wait
+    HIP_TRY(hipMemcpyAsync(c->tau.p, tau, c->tau.bytes, hipMemcpyDefault, c->ctx->stream));
+    if (clip_id) HIP_TRY(hipMemcpyAsync(c->clip.p, clip_id, c->clip.bytes, hipMemcpyDefault, c->ctx->stream));
+    c->mw_stale = true;
+    return SKINRT_OK;
+}
+
+int skinrt_advance_clocks(skinrt_crowd* c, float dt, const float* dev_rate) {
+    if (int rc = check_crowd(c)) return rc;
+    if (!std::isfinite(dt)) return fail(SKINRT_E_INVALID, "dt is not finite");
+    HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+    HIP_TRY(launch_advance_clocks(c->rig->dev, c->tau.as<float>(), c->clip.as<uint32_t>(), c->I, dt, dev_rate, c->ctx->stream));
+    c->mw_stale = true;
     return SKINRT_OK;
 }
 
@@ -479,6 +541,7 @@ int skinrt_set_morph_weights(skinrt_crowd* c, const float* weights) {
     if (weights) HIP_TRY(hipMemcpyAsync(c->mw.p, weights, c->mw.bytes, hipMemcpyHostToDevice, c->ctx->stream));
     else HIP_TRY(launch_fill_morph_weights(c->mw.as<float>(), c->rig->default_mw.as<float>(), c->I, M, c->ctx->stream));
     HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    c->mw_stale = true;
     return SKINRT_OK;
 }
 
@@ -515,17 +578,20 @@ int skinrt_evaluate(skinrt_crowd* c, uint32_t mask) {
     const RigDev& rig = c->rig->dev;
     const CrowdDev cr = c->dev();
     HIP_TRY(hipEventRecord(c->ev[0], s));
-    if (mask & SKINRT_STAGE_POSE) {
-        HIP_TRY(launch_pose(rig, cr, c->ctx->cfg.cubic_quirk ? 1u : 0u, c->pose_path, c->local_t.as<float>(), s));
-        if (c->mw_eff.p) HIP_TRY(launch_sample_weights(rig, cr, c->mw_eff.as<float>(), c->ctx->cfg.cubic_quirk ? 1u : 0u, s));
+    if (mask & SKINRT_STAGE_POSE) HIP_TRY(launch_pose(rig, cr, c->ctx->cfg.cubic_quirk ? 1u : 0u, c->pose_path, c->local_t.as<float>(), s));
+    // the weights the skin stage reads on rigs with weights channels: sampled with the pose, and again in front of a
+    // skin stage that runs without one after the host changed weights, clocks or clips
+    if (c->mw_eff.p && ((mask & SKINRT_STAGE_POSE) || ((mask & SKINRT_STAGE_SKIN) && c->mw_stale))) {
+        HIP_TRY(launch_sample_weights(rig, cr, c->mw_eff.as<float>(), c->ctx->cfg.cubic_quirk ? 1u : 0u, s));
+        c->mw_stale = false;
     }
     HIP_TRY(hipEventRecord(c->ev[1], s));
     if (mask & SKINRT_STAGE_SKIN) {
         SkinPlan p = c->plan;
         p.aabb = (mask & SKINRT_STAGE_AABB) ? 1 : 0;
         SkinConcurrency conc{c->ctx->side, c->ev[4], c->ev[5]};
-        if (const char* ov = std::getenv("SKINRT_FIX_ORDER")) conc.skin2_first = (uint32_t)std::atoi(ov);
-        if (const char* bv = std::getenv("SKINRT_FIX_BLOCKS")) conc.fix_blocks = (uint32_t)std::max(1, std::atoi(bv));
+        conc.skin2_first = c->ctx->env.fix_order;
+        conc.fix_blocks = c->ctx->env.fix_blocks;
         HIP_TRY(launch_skin(rig, cr, p, s, conc));
     }
     HIP_TRY(hipEventRecord(c->ev[2], s));
@@ -573,6 +639,22 @@ int skinrt_get_aabbs(skinrt_crowd* c, float** o, uint64_t* n) { return c ? get_b
 int skinrt_get_palette(skinrt_crowd* c, float** o, uint64_t* n) { return c ? get_buf(c, c->palette, 4, (void**)o, n) : check_crowd(c); }
 int skinrt_get_world(skinrt_crowd* c, float** o, uint64_t* n) { return c ? get_buf(c, c->world, 4, (void**)o, n) : check_crowd(c); }
 int skinrt_get_keyframe_index(skinrt_crowd* c, uint32_t** o, uint64_t* n) { return c ? get_buf(c, c->keyidx, 4, (void**)o, n) : check_crowd(c); }
+int skinrt_get_clocks(skinrt_crowd* c, float** o, uint64_t* n) { return c ? get_buf(c, c->tau, 4, (void**)o, n) : check_crowd(c); }
+
+int skinrt_rig_skin_layout(skinrt_rig* rig, uint32_t skin, skinrt_skin_layout* out) {
+    if (!rig || !out) return fail(SKINRT_E_INVALID, "skinrt_rig_skin_layout: NULL argument");
+    if (skin >= rig->host.skins.size()) return fail(SKINRT_E_RANGE, "skin index out of range");
+    out->first_palette_entry = rig->host.skins[skin].first;
+    out->joint_count = rig->host.skins[skin].count;
+    return SKINRT_OK;
+}
+
+int skinrt_rig_section_layout(skinrt_rig* rig, uint32_t section, skinrt_section_layout* out) {
+    if (!rig || !out) return fail(SKINRT_E_INVALID, "skinrt_rig_section_layout: NULL argument");
+    if (section >= rig->host.sections.size()) return fail(SKINRT_E_RANGE, "section index out of range");
+    *out = rig->host.sections[section];
+    return SKINRT_OK;
+}
 
 int skinrt_download(skinrt_ctx* ctx, const void* dev_src, void* host_dst, uint64_t bytes) {
     if (!ctx) return fail(SKINRT_E_INVALID, "ctx is NULL");
@@ -584,15 +666,41 @@ int skinrt_download(skinrt_ctx* ctx, const void* dev_src, void* host_dst, uint64
     return SKINRT_OK;
 }
 
-int skinrt_export_skin_uniform(skinrt_crowd* c, uint32_t instance, void* dst) {
+namespace {
+
+// the skin's span of the palette, or a failure code; a rig without skins has nothing to export
+int skin_span(skinrt_crowd* c, uint32_t skin, SkinSpan* out) {
+    const CompiledRig& h = c->rig->host;
+    if (skin >= h.skins.size()) {
+        if (skin == 0) { *out = SkinSpan{0, 0}; return SKINRT_OK; }  // no skin at all: an all-zero palette, as J = 0 always gave
+        return fail(SKINRT_E_RANGE, "skin index out of range");
+    }
+    *out = h.skins[skin];
+    // assert!(items.len() <= MAX_JOINTS) — renderer/src/renderer/uniform/skin.rs:40,60
+    if (out->count > SKINRT_MAX_JOINTS_REFERENCE) return fail(SKINRT_E_LIMIT, "the reference palette holds at most 128 joints");
+    return SKINRT_OK;
+}
+
+struct VertexSpan { uint32_t first, count; };
+int section_span(skinrt_crowd* c, int64_t section, VertexSpan* out) {
+    const CompiledRig& h = c->rig->host;
+    if (section < 0) { *out = VertexSpan{0, h.V}; return SKINRT_OK; }  // the whole mesh
+    if ((uint64_t)section >= h.sections.size()) return fail(SKINRT_E_RANGE, "section index out of range");
+    const skinrt_section_layout& sc = h.sections[(size_t)section];
+    if (sc.skin < 0) return fail(SKINRT_E_INVALID, "an un-skinned section has no skin vertex layout (use the static mesh and skinrt_export_instance_uniform)");
+    *out = VertexSpan{sc.first_vertex, sc.vertex_count};
+    return SKINRT_OK;
+}
+
+int export_skin_uniform_host(skinrt_crowd* c, uint32_t skin, uint32_t instance, void* dst) {
     if (int rc = check_crowd(c)) return rc;
     if (!dst) return fail(SKINRT_E_INVALID, "dst is NULL");
     if (instance >= c->I) return fail(SKINRT_E_RANGE, "instance out of range");
-    const uint32_t J = c->rig->host.J;
-    // assert!(items.len() <= MAX_JOINTS) — renderer/src/renderer/uniform/skin.rs:40,60
-    if (J > SKINRT_MAX_JOINTS_REFERENCE) return fail(SKINRT_E_LIMIT, "the reference palette holds at most 128 joints");
+    SkinSpan sp;
+    if (int rc = skin_span(c, skin, &sp)) return rc;
+    const uint32_t P = c->rig->host.J, J = sp.count;
     std::vector<float> rows((size_t)J * kPalFloats);
-    if (int rc = skinrt_download(c->ctx, c->palette.as<float>() + (size_t)instance * J * kPalFloats, rows.data(), rows.size() * 4)) return rc;
+    if (int rc = skinrt_download(c->ctx, c->palette.as<float>() + ((size_t)instance * P + sp.first) * kPalFloats, rows.data(), rows.size() * 4)) return rc;
     float* out = static_cast<float*>(dst);
     std::memset(out, 0, (size_t)SKINRT_MAX_JOINTS_REFERENCE * SKINRT_SKIN_MATRIX_BYTES);
     for (uint32_t j = 0; j < J; ++j) {
@@ -610,15 +718,17 @@ int skinrt_export_skin_uniform(skinrt_crowd* c, uint32_t instance, void* dst) {
     return SKINRT_OK;
 }
 
-int skinrt_export_interleaved(skinrt_crowd* c, uint32_t instance, uint32_t layout, const float* attr, void* dst) {
+int export_interleaved_host(skinrt_crowd* c, int64_t section, uint32_t instance, uint32_t layout, const float* attr, void* dst) {
     if (int rc = check_crowd(c)) return rc;
     if (!dst) return fail(SKINRT_E_INVALID, "dst is NULL");
     if (instance >= c->I) return fail(SKINRT_E_RANGE, "instance out of range");
     if (layout > SKINRT_LAYOUT_TEXTURE_SKIN) return fail(SKINRT_E_INVALID, "unknown vertex layout");
+    VertexSpan vs;
+    if (int rc = section_span(c, section, &vs)) return rc;
     const CompiledRig& h = c->rig->host;
-    const size_t V = h.V;
+    const size_t V = vs.count;
     std::vector<float> p(V * 3), n(V * 3), t(V * 3);
-    const size_t off = (size_t)instance * V * 3;
+    const size_t off = ((size_t)instance * h.V + vs.first) * 3;
     if (int rc = skinrt_download(c->ctx, c->pos.as<float>() + off, p.data(), V * 12)) return rc;
     if (int rc = skinrt_download(c->ctx, c->nrm.as<float>() + off, n.data(), V * 12)) return rc;
     if (int rc = skinrt_download(c->ctx, c->tan.as<float>() + off, t.data(), V * 12)) return rc;
@@ -632,35 +742,94 @@ int skinrt_export_interleaved(skinrt_crowd* c, uint32_t instance, uint32_t layou
         q += na * 4;
         std::memcpy(q, &n[v * 3], 12); q += 12;
         std::memcpy(q, &t[v * 3], 12); q += 12;
-        std::memcpy(q, &h.joints0[v * 4], 8); q += 8;
-        std::memcpy(q, &h.weights0[v * 4], 16);
+        std::memcpy(q, &h.joints0[(vs.first + v) * 4], 8); q += 8;
+        std::memcpy(q, &h.weights0[(vs.first + v) * 4], 16);
     }
     return SKINRT_OK;
 }
 
-int skinrt_export_skin_uniform_device(skinrt_crowd* c, uint32_t first, uint32_t count, void* dev_dst) {
+int export_skin_uniform_dev(skinrt_crowd* c, uint32_t skin, uint32_t first, uint32_t count, void* dev_dst) {
     if (int rc = check_crowd(c)) return rc;
     if (count == 0) return SKINRT_OK;
     if (!dev_dst) return fail(SKINRT_E_INVALID, "dev_dst is NULL");
     if (reinterpret_cast<uintptr_t>(dev_dst) & 15u) return fail(SKINRT_E_INVALID, "dev_dst must be 16-byte aligned");
     if ((uint64_t)first + count > c->I) return fail(SKINRT_E_RANGE, "instance range out of range");
-    // assert!(items.len() <= MAX_JOINTS) — renderer/src/renderer/uniform/skin.rs:40,60
-    if (c->rig->host.J > SKINRT_MAX_JOINTS_REFERENCE) return fail(SKINRT_E_LIMIT, "the reference palette holds at most 128 joints");
+    SkinSpan sp;
+    if (int rc = skin_span(c, skin, &sp)) return rc;
     HIP_TRY(hipSetDevice(c->ctx->cfg.device));
-    HIP_TRY(launch_export_skin_uniform(c->dev(), c->rig->host.J, first, count, dev_dst, c->ctx->stream));
+    HIP_TRY(launch_export_skin_uniform(c->dev(), c->rig->host.J, sp.first, sp.count, first, count, dev_dst, c->ctx->stream));
     return SKINRT_OK;
 }
 
-int skinrt_export_interleaved_device(skinrt_crowd* c, uint32_t first, uint32_t count, uint32_t layout, const float* dev_attr, void* dev_dst) {
+int export_interleaved_dev(skinrt_crowd* c, int64_t section, uint32_t first, uint32_t count, uint32_t layout, const float* dev_attr, void* dev_dst) {
     if (int rc = check_crowd(c)) return rc;
     if (layout > SKINRT_LAYOUT_TEXTURE_SKIN) return fail(SKINRT_E_INVALID, "unknown vertex layout");
-    if (count == 0) return SKINRT_OK;
+    VertexSpan vs;
+    if (int rc = section_span(c, section, &vs)) return rc;
+    if (count == 0 || vs.count == 0) return SKINRT_OK;
     if (!dev_dst) return fail(SKINRT_E_INVALID, "dev_dst is NULL");
     if (reinterpret_cast<uintptr_t>(dev_dst) & 15u) return fail(SKINRT_E_INVALID, "dev_dst must be 16-byte aligned");
     if ((uint64_t)first + count > c->I) return fail(SKINRT_E_RANGE, "instance range out of range");
     HIP_TRY(hipSetDevice(c->ctx->cfg.device));
-    HIP_TRY(launch_export_interleaved(c->dev(), c->rig->host.V, c->rig->joints0_dev, c->rig->weights0_dev, dev_attr, layout, first, count,
-                                      dev_dst, c->ctx->stream));
+    HIP_TRY(launch_export_interleaved(c->dev(), c->rig->host.V, vs.first, vs.count, c->rig->joints0_dev, c->rig->weights0_dev, dev_attr, layout,
+                                      first, count, dev_dst, c->ctx->stream));
+    return SKINRT_OK;
+}
+
+}  // namespace
+
+int skinrt_export_skin_uniform(skinrt_crowd* c, uint32_t instance, void* dst) { return export_skin_uniform_host(c, 0, instance, dst); }
+int skinrt_export_skin_uniform_of(skinrt_crowd* c, uint32_t skin, uint32_t instance, void* dst) { return export_skin_uniform_host(c, skin, instance, dst); }
+int skinrt_export_interleaved(skinrt_crowd* c, uint32_t instance, uint32_t layout, const float* attr, void* dst) {
+    return export_interleaved_host(c, -1, instance, layout, attr, dst);
+}
+int skinrt_export_interleaved_section(skinrt_crowd* c, uint32_t section, uint32_t instance, uint32_t layout, const float* attr, void* dst) {
+    return export_interleaved_host(c, section, instance, layout, attr, dst);
+}
+int skinrt_export_skin_uniform_device(skinrt_crowd* c, uint32_t first, uint32_t count, void* dev_dst) {
+    return export_skin_uniform_dev(c, 0, first, count, dev_dst);
+}
+int skinrt_export_skin_uniform_of_device(skinrt_crowd* c, uint32_t skin, uint32_t first, uint32_t count, void* dev_dst) {
+    return export_skin_uniform_dev(c, skin, first, count, dev_dst);
+}
+int skinrt_export_interleaved_device(skinrt_crowd* c, uint32_t first, uint32_t count, uint32_t layout, const float* dev_attr, void* dev_dst) {
+    return export_interleaved_dev(c, -1, first, count, layout, dev_attr, dev_dst);
+}
+int skinrt_export_interleaved_section_device(skinrt_crowd* c, uint32_t section, uint32_t first, uint32_t count, uint32_t layout,
+                                             const float* dev_attr, void* dev_dst) {
+    return export_interleaved_dev(c, section, first, count, layout, dev_attr, dev_dst);
+}
+
+int skinrt_export_instance_uniform_device(skinrt_crowd* c, uint32_t first, uint32_t count, const uint32_t* dev_nodes, uint32_t node_count,
+                                          uint32_t stride, void* dev_dst) {
+    if (int rc = check_crowd(c)) return rc;
+    if (count == 0 || node_count == 0) return SKINRT_OK;
+    if (!dev_nodes || !dev_dst) return fail(SKINRT_E_INVALID, "skinrt_export_instance_uniform_device: NULL pointer");
+    if (stride < SKINRT_INSTANCE_UNIFORM_BYTES || (stride & 3u)) return fail(SKINRT_E_INVALID, "stride must be >= 124 and a multiple of 4");
+    if (reinterpret_cast<uintptr_t>(dev_dst) & 3u) return fail(SKINRT_E_INVALID, "dev_dst must be 4-byte aligned");
+    if ((uint64_t)first + count > c->I) return fail(SKINRT_E_RANGE, "instance range out of range");
+    HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+    HIP_TRY(launch_export_instance_uniform(c->dev(), c->rig->host.N, first, count, dev_nodes, node_count, stride, dev_dst, c->ctx->stream));
+    return SKINRT_OK;
+}
+
+int skinrt_export_instance_uniform(skinrt_crowd* c, uint32_t instance, uint32_t node, void* dst) {
+    if (int rc = check_crowd(c)) return rc;
+    if (!dst) return fail(SKINRT_E_INVALID, "dst is NULL");
+    if (instance >= c->I) return fail(SKINRT_E_RANGE, "instance out of range");
+    if (node >= c->rig->host.N) return fail(SKINRT_E_RANGE, "node out of range");
+    // the device exporter on one record, through a small staging buffer: ONE implementation of the arithmetic
+    HIP_TRY(hipSetDevice(c->ctx->cfg.device));
+    DevBuf stage;
+    HIP_TRY(stage.alloc(128 + 16));
+    hipError_t e = hipMemcpyAsync(stage.p, &node, 4, hipMemcpyHostToDevice, c->ctx->stream);
+    if (e == hipSuccess)
+        e = launch_export_instance_uniform(c->dev(), c->rig->host.N, instance, 1, stage.as<uint32_t>(), 1, SKINRT_INSTANCE_UNIFORM_BYTES,
+                                           stage.as<char>() + 16, c->ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, stage.as<char>() + 16, SKINRT_INSTANCE_UNIFORM_BYTES, hipMemcpyDeviceToHost, c->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->ctx->stream);
+    stage.release();
+    if (e != hipSuccess) return fail(SKINRT_E_DEVICE, std::string("skinrt_export_instance_uniform: ") + hipGetErrorString(e));
     return SKINRT_OK;
 }
 

@@ -20,8 +20,9 @@ struct RigDev {
     const int32_t* node_chan;
     const ChanRec* chans;
     const uint32_t* clip_chan_count;
-    const int32_t* clip_weights_chan;  // [clips] the clip's SKINRT_PATH_WEIGHTS channel, or -1
+    const WeightSrc* weight_src;       // [clips][M] the SKINRT_PATH_WEIGHTS channel that drives target m in that clip, or chan = -1
     uint32_t weight_channel_clips;     // clips that have one (0: CrowdDev::mw_in is never used)
+    const float* clip_length;          // [clips] largest key time (skinrt_advance_clocks)
     const float* times;
     const float* values;
     const uint32_t* joint_node;
@@ -111,13 +112,23 @@ enum PosePath : uint32_t { kPoseWave = 0, kPoseSplit = 1 };
 // local_t: [N][I][12] scratch for the lane-per-instance channel sampling, or nullptr (sampling inside the pose kernels)
 hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t cubic_quirk, PosePath path, float* local_t, hipStream_t s);
 hipError_t launch_sample_weights(const RigDev& rig, const CrowdDev& cr, float* mw_out, uint32_t quirk, hipStream_t s);
+// tau[i] = fmodf(tau[i] + dt * rate[i], clip_length[clip[i]]) (skinrt_advance_clocks)
+hipError_t launch_advance_clocks(const RigDev& rig, float* tau, const uint32_t* clip, uint32_t I, float dt, const float* rate, hipStream_t s);
+// InstanceUniform records (uniform/transform.rs:8-14) of the listed nodes for instances [first, first + count)
+hipError_t launch_export_instance_uniform(const CrowdDev& cr, uint32_t N, uint32_t first, uint32_t count, const uint32_t* nodes,
+                                          uint32_t node_count, uint32_t stride, void* dst, hipStream_t s);
 // kernels_skin.hip
 hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s, const SkinConcurrency& conc);
 hipError_t launch_aabb_reduce(const RigDev& rig, const CrowdDev& cr, hipStream_t s);
+uint32_t skin_build_flags();  // SKINRT_BUILD_* bits of the skin kernels' translation unit
 // kernels_export.hip: reference-layout records written on the device (instances [first, first + count))
-hipError_t launch_export_interleaved(const CrowdDev& cr, uint32_t V, const uint32_t* joints0, const float* weights0, const float* attr,
-                                     uint32_t layout, uint32_t first, uint32_t count, void* dst, hipStream_t s);
-hipError_t launch_export_skin_uniform(const CrowdDev& cr, uint32_t J, uint32_t first, uint32_t count, void* dst, hipStream_t s);
+// vertices [v_first, v_first + v_count) of every instance's V (a section, or the whole mesh); attr counts from v_first
+hipError_t launch_export_interleaved(const CrowdDev& cr, uint32_t V, uint32_t v_first, uint32_t v_count, const uint32_t* joints0,
+                                     const float* weights0, const float* attr, uint32_t layout, uint32_t first, uint32_t count, void* dst,
+                                     hipStream_t s);
+// palette entries [j_first, j_first + j_count) of every instance's P entries (one skin's joints), j_count <= 128
+hipError_t launch_export_skin_uniform(const CrowdDev& cr, uint32_t P, uint32_t j_first, uint32_t j_count, uint32_t first, uint32_t count,
+                                      void* dst, hipStream_t s);
 // kernels_geom.hip: calculate_tangent on the device (load time)
 size_t tangent_work_bytes(uint32_t vertices, uint32_t corners);
 hipError_t tangent_static_setup(int device);                             // once per device, that device current

@@ -13,13 +13,16 @@ namespace skinrt {
 
 namespace {
 
+// The exported vertices are a span [v_first, v_first + V) of every instance's Vall vertices (one section of the rig, or
+// the whole mesh); pos / nrm / tan / joints0 / weights0 arrive already offset to the span's first vertex.
 struct ExportSrc {
-    const float* pos;        // [I][V][3]
+    const float* pos;        // [I][Vall][3] + v_first * 3
     const float* nrm;
     const float* tan;
     const float* attr;       // [V][na] or nullptr (zeros)
     const uint32_t* joints0; // [V][2]: four u16 joint indices of weight set 0, as stored by the loader
     const float* weights0;   // [V][4]
+    uint32_t Vall;           // vertices per instance in pos / nrm / tan
 };
 
 // Block = 256 vertices x a group of kExportGroup consecutive instances.  The shared per-vertex tables (caller's colour /
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void k_export_interleaved(const ExportSrc src,
     for (int r = 0; r < 3; ++r) { const uint32_t d = tid + 256u * r; slot[r] = (d / 3) * S + d % 3; }
     float x[3][3];
     auto fetch = [&](uint32_t k) {
-        const size_t inst_off = (size_t)(first + k) * V * 3 + (size_t)v0 * 3;
+        const size_t inst_off = (size_t)(first + k) * src.Vall * 3 + (size_t)v0 * 3;
         const float* arrays[3] = {src.pos + inst_off, src.nrm + inst_off, src.tan + inst_off};
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -93,7 +96,9 @@ __global__ __launch_bounds__(256) void k_export_interleaved(const ExportSrc src,
 }
 
 // One thread per (instance, palette slot): 24 floats in (joint rows, packed normal rows, padding), 28 floats out.
-__global__ __launch_bounds__(256) void k_export_skin_uniform(const float* palette, uint32_t J, uint32_t first, uint32_t count, float4* dst) {
+// The skin's joints are entries [j_first, j_first + J) of every instance's P palette entries.
+__global__ __launch_bounds__(256) void k_export_skin_uniform(const float* palette, uint32_t P, uint32_t j_first, uint32_t J, uint32_t first,
+                                                             uint32_t count, float4* dst) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g >= count * 128u) return;
     const uint32_t k = g >> 7, j = g & 127u;
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void k_export_skin_uniform(const float* palett
         for (int q = 0; q < 7; ++q) o[q] = z;
         return;
     }
-    const float4* e = reinterpret_cast<const float4*>(palette + ((size_t)(first + k) * J + j) * kPalFloats);
+    const float4* e = reinterpret_cast<const float4*>(palette + ((size_t)(first + k) * P + j_first + j) * kPalFloats);
     const float4 r0 = e[0], r1 = e[1], r2 = e[2], n0 = e[3], n1 = e[4], n2 = e[5];
     o[0] = make_float4(r0.x, r1.x, r2.x, 0.0f);  // column 0 of the 4x4, last row 0,0,0,1
     o[1] = make_float4(r0.y, r1.y, r2.y, 0.0f);
@@ -118,11 +123,13 @@ __global__ __launch_bounds__(256) void k_export_skin_uniform(const float* palett
 
 }  // namespace
 
-hipError_t launch_export_interleaved(const CrowdDev& cr, uint32_t V, const uint32_t* joints0, const float* weights0, const float* attr,
-                                     uint32_t layout, uint32_t first, uint32_t count, void* dst, hipStream_t s) {
+hipError_t launch_export_interleaved(const CrowdDev& cr, uint32_t Vall, uint32_t v_first, uint32_t V, const uint32_t* joints0,
+                                     const float* weights0, const float* attr, uint32_t layout, uint32_t first, uint32_t count, void* dst,
+                                     hipStream_t s) {
     if (count == 0 || V == 0) return hipSuccess;
-    if ((uint64_t)first + count > cr.I || (reinterpret_cast<uintptr_t>(dst) & 15u)) return hipErrorInvalidValue;
-    const ExportSrc src{cr.pos, cr.nrm, cr.tan, attr, joints0, weights0};
+    if ((uint64_t)first + count > cr.I || (uint64_t)v_first + V > Vall || (reinterpret_cast<uintptr_t>(dst) & 15u)) return hipErrorInvalidValue;
+    const size_t vo = (size_t)v_first;
+    const ExportSrc src{cr.pos + vo * 3, cr.nrm + vo * 3, cr.tan + vo * 3, attr, joints0 + vo * 2, weights0 + vo * 4, Vall};
     const uint32_t tiles = (V + 255) / 256;
     const uint32_t groups = (count + kExportGroup - 1) / kExportGroup;
     if ((uint64_t)tiles * groups > 0x7fffffffull) return hipErrorInvalidValue;
@@ -134,12 +141,14 @@ hipError_t launch_export_interleaved(const CrowdDev& cr, uint32_t V, const uint3
     return hipGetLastError();
 }
 
-hipError_t launch_export_skin_uniform(const CrowdDev& cr, uint32_t J, uint32_t first, uint32_t count, void* dst, hipStream_t s) {
+hipError_t launch_export_skin_uniform(const CrowdDev& cr, uint32_t P, uint32_t j_first, uint32_t J, uint32_t first, uint32_t count, void* dst,
+                                      hipStream_t s) {
     if (count == 0) return hipSuccess;
-    if ((uint64_t)first + count > cr.I || J > 128 || (reinterpret_cast<uintptr_t>(dst) & 15u) || (uint64_t)count * 128 > 0x7fffffffull)
+    if ((uint64_t)first + count > cr.I || J > 128 || (uint64_t)j_first + J > P || (reinterpret_cast<uintptr_t>(dst) & 15u) ||
+        (uint64_t)count * 128 > 0x7fffffffull)
         return hipErrorInvalidValue;
     const uint32_t threads = count * 128u;
-    hipLaunchKernelGGL(k_export_skin_uniform, dim3((threads + 255) / 256), dim3(256), 0, s, cr.palette, J, first, count, static_cast<float4*>(dst));
+    hipLaunchKernelGGL(k_export_skin_uniform, dim3((threads + 255) / 256), dim3(256), 0, s, cr.palette, P, j_first, J, first, count, static_cast<float4*>(dst));
     return hipGetLastError();
 }
 

@@ -19,6 +19,8 @@
 #include "device_types.hpp"
 
 #pragma clang fp contract(off)
+// the LDS-DMA statements below write m0 and say so in their clobber lists; clang warns that m0 is a reserved register
+#pragma clang diagnostic ignored "-Winline-asm"
 
 namespace skinrt {
 
@@ -170,8 +172,10 @@ __device__ Rows node_local(const RigDev& rig, uint32_t clip, bool has_clip, uint
 // a8 + a9: joint = world * inverse_bind; normal = Mat3::from_mat4(joint.inverse().transpose())
 // (renderer/src/renderer/uniform/skin.rs:30-37).  glam's cofactor inverse reduces, for an affine
 // matrix, to the 2x2 minors below (the dropped factors are *1 and -0), in the same order.
-__device__ __forceinline__ void palette_entry(const Rows& world, const Rows& ibm, float* __restrict__ out24) {
-    const Rows m = mul_affine(world, ibm);
+struct Normal9 {
+    float n00, n01, n02, n10, n11, n12, n20, n21, n22;  // nRC = row R, column C of Mat3(inverse(m)^T)
+};
+__device__ __forceinline__ Normal9 normal_rows(const Rows& m) {
     // glam naming: mCR = column C, row R
     const float m00 = m.r0.x, m10 = m.r0.y, m20 = m.r0.z;
     const float m01 = m.r1.x, m11 = m.r1.y, m21 = m.r1.z;
@@ -181,12 +185,18 @@ __device__ __forceinline__ void palette_entry(const Rows& world, const Rows& ibm
     const float i20 = m10 * m21 - m11 * m20, i21 = m00 * m21 - m01 * m20, i22 = m00 * m11 - m01 * m10;
     const float dot1 = (m00 * i00 + m01 * (-i10)) + m02 * i20;
     const float rcp = 1.0f / dot1;
+    return Normal9{i00 * rcp, (-i01) * rcp, i02 * rcp, (-i10) * rcp, i11 * rcp, (-i12) * rcp, i20 * rcp, (-i21) * rcp, i22 * rcp};
+}
+
+__device__ __forceinline__ void palette_entry(const Rows& world, const Rows& ibm, float* __restrict__ out24) {
+    const Rows m = mul_affine(world, ibm);
+    const Normal9 n = normal_rows(m);
     float4* o = reinterpret_cast<float4*>(out24);
     o[0] = m.r0; o[1] = m.r1; o[2] = m.r2;
     // normal rows packed: 9 floats, so that the skin kernels fetch them as 2 x 16 bytes + 4 bytes per influence
-    o[3] = make_float4(i00 * rcp, (-i01) * rcp, i02 * rcp, (-i10) * rcp);
-    o[4] = make_float4(i11 * rcp, (-i12) * rcp, i20 * rcp, (-i21) * rcp);
-    o[5] = make_float4(i22 * rcp, 0.0f, 0.0f, 0.0f);
+    o[3] = make_float4(n.n00, n.n01, n.n02, n.n10);
+    o[4] = make_float4(n.n11, n.n12, n.n20, n.n21);
+    o[5] = make_float4(n.n22, 0.0f, 0.0f, 0.0f);
 }
 
 __device__ __forceinline__ void clear_unused_keys(const RigDev& rig, uint32_t clip, bool has_clip,
@@ -384,13 +394,13 @@ __global__ __launch_bounds__(128) void k_propagate_ring(const RigDev rig, const 
                 const uint32_t inst = min(i0 + q / 3, I - 1);  // a block's idle instances shadow the last real one
                 const uint32_t voff = (nd * I + inst) * 48 + (q % 3) * 16;
                 const uint32_t ldsb = slot + k * 1024;
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(gbase), "s"(ldsb) : "memory");
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(gbase), "s"(ldsb) : "memory", "m0");
             }
             {
                 const int32_t* pbase = rig.parent + c0;
                 const uint32_t voff = min(lane, N - 1 - c0) * 4;
                 const uint32_t ldsb = slot + kRingChunk * 192;
-                if (lane < 16) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(pbase), "s"(ldsb) : "memory");
+                if (lane < 16) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(pbase), "s"(ldsb) : "memory", "m0");
             }
         };
         for (uint32_t j = 0; j < (uint32_t)kRingDepth; ++j) issue(j);
@@ -490,10 +500,14 @@ __global__ __launch_bounds__(256) void k_palette(const RigDev rig, const CrowdDe
 __global__ __launch_bounds__(256) void k_sample_weights(const RigDev rig, const CrowdDev cr, float* __restrict__ mw_out, const uint32_t quirk) {
     const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= (uint64_t)cr.I * rig.M) return;
-    const uint32_t i = (uint32_t)(g / rig.M), m = (uint32_t)(g - (uint64_t)i * rig.M), M = rig.M;
+    const uint32_t i = (uint32_t)(g / rig.M), mt = (uint32_t)(g - (uint64_t)i * rig.M);
     const uint32_t clip = cr.clip[i];
-    const int32_t c = clip < rig.clips ? rig.clip_weights_chan[clip] : -1;
+    WeightSrc ws{-1, 0, 0};
+    if (clip < rig.clips) ws = rig.weight_src[(size_t)clip * rig.M + mt];
+    const int32_t c = ws.chan;
     if (c < 0) { mw_out[g] = cr.mw_in[g]; return; }
+    // the channel's keys are M floats wide, M = the targets of ITS mesh section; m = this target's component
+    const uint32_t M = ws.width, m = mt - ws.first;
     const ChanRec ch = rig.chans[c];
     const float* tm = rig.times + ch.time_off;
     const float* v = rig.values + ch.value_off;
@@ -544,12 +558,72 @@ __global__ __launch_bounds__(256) void k_sample_weights(const RigDev rig, const 
     mw_out[g] = out;
 }
 
+// skinrt_advance_clocks: tau = fmodf(tau + dt * rate, clip_length) — the product and the sum round once each
+// (contraction is off in this file), fmodf is exact.  Instances at rest and clips of length 0 keep their clock.
+__global__ __launch_bounds__(256) void k_advance_clocks(float* __restrict__ tau, const uint32_t* __restrict__ clip, const float* __restrict__ clip_length,
+                                                        const uint32_t clips, const uint32_t I, const float dt, const float* __restrict__ rate) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    const uint32_t c = clip[i];
+    if (c >= clips) return;
+    const float len = clip_length[c];
+    if (!(len > 0.0f)) return;
+    const float step = rate ? dt * rate[i] : dt;
+    tau[i] = fmodf(tau[i] + step, len);
+}
+
+// InstanceUniform{transform, normal, padding} (renderer/src/renderer/uniform/transform.rs:8-14) of node nodes[n] of
+// instance first + k: transform = the world matrix (column-major, last row 0,0,0,1), normal = the columns of
+// Mat3(inverse(transform)^T) padded with 0 (:23-34) — the palette's arithmetic (normal_rows) on the world matrix.
+__global__ __launch_bounds__(256) void k_export_instance_uniform(const float* __restrict__ world, const uint32_t N, const uint32_t first,
+                                                                 const uint32_t count, const uint32_t* __restrict__ nodes, const uint32_t node_count,
+                                                                 const uint32_t stride_dwords, float* __restrict__ dst) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (uint64_t)count * node_count) return;
+    const uint32_t k = (uint32_t)(g / node_count), q = (uint32_t)(g - (uint64_t)k * node_count);
+    const uint32_t n = nodes[q];
+    float* o = dst + g * stride_dwords;
+    if (n >= N) {
+        for (int e = 0; e < 31; ++e) o[e] = 0.0f;
+        return;
+    }
+    const Rows m = load_rows(world + ((size_t)(first + k) * N + n) * 12);
+    const Normal9 nm = normal_rows(m);
+    o[0] = m.r0.x; o[1] = m.r1.x; o[2] = m.r2.x; o[3] = 0.0f;
+    o[4] = m.r0.y; o[5] = m.r1.y; o[6] = m.r2.y; o[7] = 0.0f;
+    o[8] = m.r0.z; o[9] = m.r1.z; o[10] = m.r2.z; o[11] = 0.0f;
+    o[12] = m.r0.w; o[13] = m.r1.w; o[14] = m.r2.w; o[15] = 1.0f;
+    o[16] = nm.n00; o[17] = nm.n10; o[18] = nm.n20; o[19] = 0.0f;  // column 0 of the normal matrix, pad_vec3
+    o[20] = nm.n01; o[21] = nm.n11; o[22] = nm.n21; o[23] = 0.0f;
+    o[24] = nm.n02; o[25] = nm.n12; o[26] = nm.n22; o[27] = 0.0f;
+    o[28] = 0.0f; o[29] = 0.0f; o[30] = 0.0f;                       // padding: [u8; 12]
+}
+
 }  // namespace
+
+hipError_t launch_advance_clocks(const RigDev& rig, float* tau, const uint32_t* clip, uint32_t I, float dt, const float* rate, hipStream_t s) {
+    if (I == 0 || rig.clips == 0) return hipSuccess;
+    if (!tau || !clip || !rig.clip_length) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_advance_clocks, dim3((I + 255) / 256), dim3(256), 0, s, tau, clip, rig.clip_length, rig.clips, I, dt, rate);
+    return hipGetLastError();
+}
+
+hipError_t launch_export_instance_uniform(const CrowdDev& cr, uint32_t N, uint32_t first, uint32_t count, const uint32_t* nodes,
+                                          uint32_t node_count, uint32_t stride, void* dst, hipStream_t s) {
+    const uint64_t n = (uint64_t)count * node_count;
+    if (n == 0) return hipSuccess;
+    if ((uint64_t)first + count > cr.I || !nodes || !dst || stride < SKINRT_INSTANCE_UNIFORM_BYTES || (stride & 3u) ||
+        (reinterpret_cast<uintptr_t>(dst) & 3u) || (n + 255) / 256 > 0x7fffffffull)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_export_instance_uniform, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, cr.world, N, first, count, nodes, node_count,
+                       stride / 4, static_cast<float*>(dst));
+    return hipGetLastError();
+}
 
 hipError_t launch_sample_weights(const RigDev& rig, const CrowdDev& cr, float* mw_out, uint32_t quirk, hipStream_t s) {
     const uint64_t n = (uint64_t)cr.I * rig.M;
     if (n == 0) return hipSuccess;
-    if (!mw_out || !cr.mw_in || !rig.clip_weights_chan || (n + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;
+    if (!mw_out || !cr.mw_in || !rig.weight_src || (n + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_sample_weights, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, rig, cr, mw_out, quirk);
     return hipGetLastError();
 }

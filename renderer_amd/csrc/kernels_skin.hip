@@ -272,11 +272,13 @@ __device__ __forceinline__ void morph_pair(const float* src, bool dense, uint32_
 // with no register destination.  Written as asm: the compiler's wait-count pass treats an LDS-DMA
 // it can see as aliasing every later LDS read and answers with s_waitcnt vmcnt(0), which here would
 // also wait for the wave's output stores.  All waits for these loads are placed by hand.  m0 is
-// written here and nowhere else in this file (gfx9 LDS instructions do not read it), and it cannot
-// be named as a clobber.
+// written here and named as a clobber, so the compiler never keeps a value of its own live in it
+// across one of these statements (clang warns that m0 is a reserved register: silenced below, the
+// statement really does overwrite it).
+#pragma clang diagnostic ignored "-Winline-asm"
 #define SKINRT_GLDS(IMM)                                                                                  \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:" #IMM             \
-                 : : "v"(lane_bytes), "s"(gbase), "s"(lds_base) : "memory")
+                 : : "v"(lane_bytes), "s"(gbase), "s"(lds_base) : "memory", "m0")
 
 // Start the LDS-DMA of up to kMorphSlots active pairs of one instance into this wave's slots.
 // act: the instance's records {mblock float offset, weight bits, dense, region floats}.
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
 #endif
 #define SKINRT_GLDS_AT(VOFF, GBASE, LDSB)                                                               \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" SKINRT_PAL_MOD           \
-                 : : "v"(VOFF), "s"(GBASE), "s"(LDSB) : "memory")
+                 : : "v"(VOFF), "s"(GBASE), "s"(LDSB) : "memory", "m0")
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -1535,6 +1537,20 @@ void debug_dump_stamps() {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), h, sizeof h);
 }
 #endif
+
+// What this translation unit was compiled with (skinrt_build_flags): anything but 0 is a measurement build.
+uint32_t skin_build_flags() {
+    uint32_t f = 0;
+    if (SKINRT_ABLATE != 0 || SKINRT_FIX_ABLATE != 0) f |= SKINRT_BUILD_ABLATE;
+    if (SKINRT_EXP != 0) f |= SKINRT_BUILD_EXP;
+#ifdef SKINRT_STAMPS
+    f |= SKINRT_BUILD_STAMPS;
+#endif
+    if (SKINRT_RANGE2 != 80 || SKINRT_MORPH_SLOTS != 2 || SKINRT_INFLIGHT != 2 || SKINRT_BLOCKS_K1 != 5 || SKINRT_ORDER_ROT != 23u ||
+        SKINRT_STORE_POLICY != 1 || sizeof(SKINRT_PAL_MOD) != 1)
+        f |= SKINRT_BUILD_TUNING;
+    return f;
+}
 
 hipError_t launch_aabb_reduce(const RigDev& rig, const CrowdDev& cr, hipStream_t s) {
     if (cr.I == 0) return hipSuccess;

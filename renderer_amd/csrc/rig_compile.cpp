@@ -92,16 +92,98 @@ void decompose_affine(const float* m, float* t, float* q, float* s) {
 static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, CompiledRig& r) {
     REQUIRE(d != nullptr, SKINRT_E_INVALID, "rig desc is NULL");
     REQUIRE(d->struct_size == sizeof(skinrt_rig_desc), SKINRT_E_INVALID, "skinrt_rig_desc.struct_size mismatch");
-    const uint32_t N = d->node_count, J = d->joint_count, V = d->vertex_count, K = d->set_count, M = d->target_count;
-    r.N = N; r.J = J; r.V = V; r.K = K; r.M = M; r.clips = d->clip_count;
+    const uint32_t N = d->node_count, V = d->vertex_count, K = d->set_count, M = d->target_count;
+    r.N = N; r.V = V; r.K = K; r.M = M; r.clips = d->clip_count;
     REQUIRE(N >= 1, SKINRT_E_INVALID, "rig has no nodes");
     REQUIRE(d->parent && d->translation && d->rotation && d->scale, SKINRT_E_INVALID, "node arrays missing");
     REQUIRE(M <= 65535, SKINRT_E_INVALID, "more than 65535 morph targets");
-    REQUIRE(J <= 65536, SKINRT_E_INVALID, "joint indices are u16: at most 65536 joints");
-    if (cfg && cfg->reference_limits) {
-        REQUIRE(J <= SKINRT_MAX_JOINTS_REFERENCE, SKINRT_E_LIMIT, "reference_limits: more than 128 joints (uniform/skin.rs:10)");
-        REQUIRE(K <= 1, SKINRT_E_LIMIT, "reference_limits: the reference shader reads joint/weight set 0 only");
+
+    // ---- skins and sections (ABI 6): resolve the short forms ------------------------------------------
+    std::vector<skinrt_skin_desc> skins;
+    if (d->skin_count) {
+        REQUIRE(d->skins != nullptr, SKINRT_E_INVALID, "skins is NULL");
+        skins.assign(d->skins, d->skins + d->skin_count);
+    } else if (d->joint_count) {
+        skins.push_back(skinrt_skin_desc{d->joint_count, d->joint_node, d->inverse_bind});
     }
+    const bool one_section = d->section_count == 0;  // short form: a weights channel's target_node is not looked at
+    std::vector<skinrt_section_desc> secs;
+    if (!one_section) {
+        REQUIRE(d->sections != nullptr, SKINRT_E_INVALID, "sections is NULL");
+        secs.assign(d->sections, d->sections + d->section_count);
+    } else if (V || M) {
+        if (V) REQUIRE(!skins.empty(), SKINRT_E_INVALID, "skinned vertices but no joints");
+        secs.push_back(skinrt_section_desc{0u, skins.empty() ? -1 : 0, 0u, V, 0u, M});
+    }
+    uint32_t sum_joints = 0;
+    for (const skinrt_skin_desc& sk : skins) {
+        REQUIRE(sk.joint_count == 0 || sk.joint_node, SKINRT_E_INVALID, "joint_node is NULL");
+        if (cfg && cfg->reference_limits)
+            REQUIRE(sk.joint_count <= SKINRT_MAX_JOINTS_REFERENCE, SKINRT_E_LIMIT, "reference_limits: more than 128 joints (uniform/skin.rs:10)");
+        r.skins.push_back(SkinSpan{sum_joints, sk.joint_count});
+        REQUIRE(sk.joint_count <= 65536 && sum_joints + sk.joint_count <= 65536, SKINRT_E_INVALID, "joint indices are u16: at most 65536 palette entries");
+        sum_joints += sk.joint_count;
+    }
+    if (cfg && cfg->reference_limits) REQUIRE(K <= 1, SKINRT_E_LIMIT, "reference_limits: the reference shader reads joint/weight set 0 only");
+    {   // sections tile the vertices and the targets in order; un-skinned ones get a palette entry per distinct node
+        uint32_t v_next = 0, m_next = 0;
+        std::vector<uint32_t> rigid_nodes;
+        for (const skinrt_section_desc& sc : secs) {
+            REQUIRE(sc.node < N, SKINRT_E_RANGE, "section node out of range");
+            REQUIRE(sc.skin >= -1 && sc.skin < (int32_t)skins.size(), SKINRT_E_RANGE, "section skin out of range");
+            REQUIRE(sc.first_vertex == v_next && sc.vertex_count <= V - v_next, SKINRT_E_INVALID, "sections must tile the vertices in order without gaps");
+            REQUIRE(sc.first_target == m_next && sc.target_count <= M - m_next, SKINRT_E_INVALID, "sections must tile the morph targets in order without gaps");
+            v_next += sc.vertex_count;
+            m_next += sc.target_count;
+            skinrt_section_layout lay{};
+            lay.node = sc.node; lay.skin = sc.skin;
+            lay.first_vertex = sc.first_vertex; lay.vertex_count = sc.vertex_count;
+            lay.first_target = sc.first_target; lay.target_count = sc.target_count;
+            if (sc.skin >= 0) lay.first_palette_entry = r.skins[sc.skin].first;
+            else if (sc.vertex_count) {
+                size_t k = std::find(rigid_nodes.begin(), rigid_nodes.end(), sc.node) - rigid_nodes.begin();
+                if (k == rigid_nodes.size()) rigid_nodes.push_back(sc.node);
+                REQUIRE(sum_joints + rigid_nodes.size() <= 65536, SKINRT_E_INVALID, "joint indices are u16: at most 65536 palette entries");
+                lay.first_palette_entry = sum_joints + (uint32_t)k;
+            }
+            r.sections.push_back(lay);
+        }
+        REQUIRE(v_next == V, SKINRT_E_INVALID, "sections do not cover every vertex");
+        REQUIRE(m_next == M, SKINRT_E_INVALID, "sections do not cover every morph target");
+        // ---- palette: joint -> node, inverse bind rows -----------------------------------------------
+        const uint32_t J = sum_joints + (uint32_t)rigid_nodes.size();
+        r.J = J;
+        r.joint_node.resize(J);
+        r.ibm.resize((size_t)J * 12);
+        static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        uint32_t j = 0;
+        for (const skinrt_skin_desc& sk : skins)
+            for (uint32_t q = 0; q < sk.joint_count; ++q, ++j) {
+                r.joint_node[j] = sk.joint_node[q];
+                REQUIRE(r.joint_node[j] < N, SKINRT_E_RANGE, "joint_node out of range");
+                const float* m = sk.inverse_bind ? sk.inverse_bind + (size_t)q * 16 : ident;
+                REQUIRE(finite_all(m, 16), SKINRT_E_INVALID, "non-finite inverse bind matrix");
+                REQUIRE(affine_last_row(m), SKINRT_E_NONAFFINE, "inverse bind matrix last row is not 0,0,0,1");
+                rows_from_cols(m, &r.ibm[(size_t)j * 12]);
+                for (int e = 12; e < 15; ++e) r.bind_extent = std::max(r.bind_extent, std::fabs(m[e]));
+            }
+        for (uint32_t n : rigid_nodes) {
+            r.joint_node[j] = n;
+            rows_from_cols(ident, &r.ibm[(size_t)j * 12]);
+            ++j;
+        }
+    }
+    const uint32_t J = r.J;
+    {
+        const uint32_t mode = cfg ? cfg->exact_arithmetic : 0;
+        // chosen per rig (mode 0), a far-from-origin rig gets 2: positions contraction-free (their sums cancel), normals and
+        // tangents fused (3x3 rows of magnitude ~1, no translation: nothing cancels; C5 skin stage -6 %)
+        r.exact = mode == 1 ? 1u : (mode == 2 ? 0u : (r.bind_extent > kExactBindExtent ? 2u : 0u));
+    }
+    // target -> section
+    std::vector<uint32_t> target_section(M, 0);
+    for (uint32_t s = 0; s < r.sections.size(); ++s)
+        for (uint32_t m = 0; m < r.sections[s].target_count; ++m) target_section[r.sections[s].first_target + m] = s;
 
     // ---- nodes ------------------------------------------------------------------------
     r.parent.assign(d->parent, d->parent + N);
@@ -147,7 +229,8 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
     REQUIRE(r.clips == 0 || d->clips, SKINRT_E_INVALID, "clips is NULL");
     r.node_chan.assign((size_t)r.clips * N * 3, -1);
     r.clip_chan_count.resize(r.clips);
-    r.clip_weights_chan.assign(r.clips, -1);
+    r.weight_src.assign((size_t)r.clips * M, WeightSrc{-1, 0, 0});
+    r.clip_length.assign(r.clips, 0.0f);
     r.Cmax = 0;
     for (uint32_t c = 0; c < r.clips; ++c) {
         const skinrt_clip_desc& cl = d->clips[c];
@@ -163,16 +246,29 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
             REQUIRE(!wchan || M > 0, SKINRT_E_INVALID, "weights channel on a rig without morph targets");
             REQUIRE(ch.interpolation <= SKINRT_INTERP_CUBICSPLINE, SKINRT_E_INVALID, "channel interpolation invalid");
             REQUIRE(ch.key_count >= 1 && ch.times && ch.values, SKINRT_E_INVALID, "channel without keyframes");
-            const uint32_t w = wchan ? M : (ch.path == SKINRT_PATH_ROTATION ? 4 : 3);
+            uint32_t wfirst = 0, wwidth = M;  // a weights channel drives the targets of the section on its node
+            if (wchan && !one_section) {
+                wwidth = 0;
+                for (const skinrt_section_layout& sc : r.sections)
+                    if (sc.node == ch.target_node && sc.target_count) { wfirst = sc.first_target; wwidth = sc.target_count; break; }
+                REQUIRE(wwidth > 0, SKINRT_E_INVALID, "weights channel targets a node without a morphed mesh section");
+            }
+            const uint32_t w = wchan ? wwidth : (ch.path == SKINRT_PATH_ROTATION ? 4 : 3);
             const uint32_t per_key = (ch.interpolation == SKINRT_INTERP_CUBICSPLINE ? 3 : 1) * w;
             REQUIRE(finite_all(ch.times, ch.key_count), SKINRT_E_INVALID, "non-finite key time");
             for (uint32_t i = 1; i < ch.key_count; ++i)
                 REQUIRE(ch.times[i] >= ch.times[i - 1], SKINRT_E_INVALID, "key times are not sorted");
+            r.clip_length[c] = std::max(r.clip_length[c], ch.times[ch.key_count - 1]);
             if (wchan) {
-                REQUIRE(r.clip_weights_chan[c] < 0, SKINRT_E_INVALID, "two weights channels in one clip");
                 REQUIRE(finite_all(ch.values, (size_t)ch.key_count * per_key), SKINRT_E_INVALID, "non-finite morph weight key");
-                r.clip_weights_chan[c] = (int32_t)r.chans.size();
-                ++r.weight_channel_clips;
+                bool first_of_clip = true;
+                for (uint32_t m = 0; m < M; ++m) first_of_clip = first_of_clip && r.weight_src[(size_t)c * M + m].chan < 0;
+                for (uint32_t m = wfirst; m < wfirst + wwidth; ++m) {
+                    WeightSrc& ws = r.weight_src[(size_t)c * M + m];
+                    REQUIRE(ws.chan < 0, SKINRT_E_INVALID, "two weights channels of one clip drive the same mesh");
+                    ws = WeightSrc{(int32_t)r.chans.size(), (uint16_t)wfirst, (uint16_t)wwidth};
+                }
+                if (first_of_clip) ++r.weight_channel_clips;
             } else {
                 int32_t& slot = r.node_chan[((size_t)c * N + ch.target_node) * 3 + ch.path];
                 REQUIRE(slot < 0, SKINRT_E_INVALID, "two channels of one clip target the same node property");
@@ -192,26 +288,6 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
         }
     }
 
-    // ---- skin ----------------------------------------------------------------------------
-    REQUIRE(J == 0 || d->joint_node, SKINRT_E_INVALID, "joint_node is NULL");
-    r.joint_node.assign(d->joint_node, d->joint_node + J);
-    r.ibm.resize((size_t)J * 12);
-    for (uint32_t j = 0; j < J; ++j) {
-        REQUIRE(r.joint_node[j] < N, SKINRT_E_RANGE, "joint_node out of range");
-        static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-        const float* m = d->inverse_bind ? d->inverse_bind + (size_t)j * 16 : ident;
-        REQUIRE(finite_all(m, 16), SKINRT_E_INVALID, "non-finite inverse bind matrix");
-        REQUIRE(affine_last_row(m), SKINRT_E_NONAFFINE, "inverse bind matrix last row is not 0,0,0,1");
-        rows_from_cols(m, &r.ibm[(size_t)j * 12]);
-        for (int e = 12; e < 15; ++e) r.bind_extent = std::max(r.bind_extent, std::fabs(m[e]));
-    }
-    {
-        const uint32_t mode = cfg ? cfg->exact_arithmetic : 0;
-        // chosen per rig (mode 0), a far-from-origin rig gets 2: positions contraction-free (their sums cancel), normals and
-        // tangents fused (3x3 rows of magnitude ~1, no translation: nothing cancels; C5 skin stage -6 %)
-        r.exact = mode == 1 ? 1u : (mode == 2 ? 0u : (r.bind_extent > kExactBindExtent ? 2u : 0u));
-    }
-
     // ---- mesh ------------------------------------------------------------------------------
     const uint32_t TV = kTileVerts;
     const uint32_t T = (V + TV - 1) / TV;
@@ -220,10 +296,29 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
     if (V) {
         REQUIRE(d->position && d->normal && d->tangent, SKINRT_E_INVALID, "vertex arrays missing (reference: expect(\"No positions in primitive\"), loader/gltf/mod.rs:1050)");
         REQUIRE(r.tangent_stride == 3 || r.tangent_stride == 4, SKINRT_E_INVALID, "tangent_stride must be 3 or 4");
-        REQUIRE(K >= 1 && K <= 4 && d->joints && d->weights, SKINRT_E_INVALID, "need 1..4 joint/weight sets");
+        REQUIRE(K >= 1 && K <= 4, SKINRT_E_INVALID, "need 1..4 joint/weight sets");
         REQUIRE(J >= 1, SKINRT_E_INVALID, "skinned vertices but no joints");
-        for (uint32_t k = 0; k < K; ++k) REQUIRE(d->joints[k] && d->weights[k], SKINRT_E_INVALID, "joint/weight set is NULL");
+        bool any_skinned = false;
+        for (const skinrt_section_layout& sc : r.sections) any_skinned = any_skinned || (sc.skin >= 0 && sc.vertex_count);
+        if (any_skinned) {
+            REQUIRE(d->joints && d->weights, SKINRT_E_INVALID, "need 1..4 joint/weight sets");
+            for (uint32_t k = 0; k < K; ++k) REQUIRE(d->joints[k] && d->weights[k], SKINRT_E_INVALID, "joint/weight set is NULL");
+        }
     }
+    // influence a = 4k + c of vertex v as (weight, palette entry): a skinned section's indices count from its skin's
+    // first entry; an un-skinned section is weight 1 on its node's entry and nothing else — S = 1 * M (+ 0 * M ...),
+    // i.e. instance.transform (shader.wgsl:148)
+    std::vector<uint32_t> vertex_section(V, 0);
+    for (uint32_t s = 0; s < r.sections.size(); ++s)
+        std::fill_n(vertex_section.begin() + r.sections[s].first_vertex, r.sections[s].vertex_count, s);
+    struct Infl { float w; uint32_t j; bool checked; };
+    auto influence = [&](uint32_t v, uint32_t k, uint32_t c) -> Infl {
+        const skinrt_section_layout& sc = r.sections[vertex_section[v]];
+        if (sc.skin < 0) return Infl{(k == 0 && c == 0) ? 1.0f : 0.0f, sc.first_palette_entry, true};
+        const float w = d->weights[k][(size_t)v * 4 + c];
+        const uint32_t j = d->joints[k][(size_t)v * 4 + c];
+        return Infl{w, sc.first_palette_entry + j, j < r.skins[sc.skin].count};
+    };
     const uint32_t W = 4 * K;
     r.base.assign((size_t)T * 9 * TV, 0.0f);
     r.wts.assign((size_t)T * W * TV, 0.0f);
@@ -249,14 +344,18 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
         for (uint32_t v = v0; v < v1; ++v)
             for (uint32_t k = 0; k < K; ++k)
                 for (uint32_t c = 0; c < 4; ++c) {
-                    const float w = d->weights[k][(size_t)v * 4 + c];
-                    const uint32_t j = d->joints[k][(size_t)v * 4 + c];
+                    const Infl in = influence(v, k, c);
+                    const float w = in.w;
+                    const uint32_t j = in.j;
                     REQUIRE(std::isfinite(w), SKINRT_E_INVALID, "non-finite joint weight");
                     if (w == 0.0f) continue;  // contributes exactly 0 whatever the index
-                    REQUIRE(j < J, SKINRT_E_RANGE, "vertex joint index out of range");
+                    REQUIRE(in.checked, SKINRT_E_RANGE, "vertex joint index out of range");
                     if (stamp[j] != t) { stamp[j] = t; list.push_back(j); }
                 }
-        if (list.empty() && J) { list.push_back(0); stamp[0] = t; }
+        if (list.empty() && J) {  // every weight of the tile is zero: any entry of its first vertex's own skin will do
+            const uint32_t j0 = r.sections[vertex_section[v0]].first_palette_entry;
+            list.push_back(j0); stamp[j0] = t;
+        }
         std::sort(list.begin(), list.end());
         for (uint32_t i = 0; i < list.size(); ++i) local_of[list[i]] = i;
         const bool lds = list.size() <= kTileJointCap;
@@ -275,8 +374,9 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
         for (uint32_t v = v0; v < v1; ++v)
             for (uint32_t k = 0; k < K; ++k)
                 for (uint32_t c = 0; c < 4; ++c) {
-                    const float w = d->weights[k][(size_t)v * 4 + c];
-                    const uint32_t j = d->joints[k][(size_t)v * 4 + c];
+                    const Infl in = influence(v, k, c);
+                    const float w = in.w;
+                    const uint32_t j = in.j;
                     const uint32_t a = k * 4 + c, l = v - v0;
                     wt[a * TV + l] = w;
                     // zero-weight influences read the tile's first joint: 0 * finite = 0 either way
@@ -307,8 +407,13 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
             }
     r.skip_sets = K == 2 && r.skippable_set_waves * 8 >= r.extra_set_waves && r.skippable_set_waves > 0;
     if (V) {
-        r.joints0.assign(d->joints[0], d->joints[0] + (size_t)V * 4);
-        r.weights0.assign(d->weights[0], d->weights[0] + (size_t)V * 4);
+        r.joints0.assign((size_t)V * 4, 0);
+        r.weights0.assign((size_t)V * 4, 0.0f);
+        for (const skinrt_section_layout& sc : r.sections)
+            if (sc.skin >= 0 && sc.vertex_count) {
+                std::copy_n(d->joints[0] + (size_t)sc.first_vertex * 4, (size_t)sc.vertex_count * 4, r.joints0.begin() + (size_t)sc.first_vertex * 4);
+                std::copy_n(d->weights[0] + (size_t)sc.first_vertex * 4, (size_t)sc.vertex_count * 4, r.weights0.begin() + (size_t)sc.first_vertex * 4);
+            }
     }
 
     // ---- morph targets -> per-vertex lists (targets ascending) ----------------------------
@@ -328,15 +433,17 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
     r.morph_entries = 0;
     for (uint32_t m = 0; m < M; ++m) {
         const skinrt_morph_target_desc& tg = d->targets[m];
-        if (!tg.indices) REQUIRE(tg.count == V, SKINRT_E_INVALID, "dense morph target count != vertex_count");
+        const skinrt_section_layout& sc = r.sections[target_section[m]];  // rows and indices count from the section's first vertex
+        if (!tg.indices) REQUIRE(tg.count == sc.vertex_count, SKINRT_E_INVALID, "dense morph target count != vertex_count");
         uint32_t prev = 0;
         for (uint32_t row = 0; row < tg.count; ++row) {
-            const uint32_t v = tg.indices ? tg.indices[row] : row;
+            const uint32_t lv = tg.indices ? tg.indices[row] : row;
             if (tg.indices) {
-                REQUIRE(v < V, SKINRT_E_RANGE, "morph target vertex index out of range");
-                REQUIRE(row == 0 || v > prev, SKINRT_E_INVALID, "morph target indices must be strictly increasing");
-                prev = v;
+                REQUIRE(lv < sc.vertex_count, SKINRT_E_RANGE, "morph target vertex index out of range");
+                REQUIRE(row == 0 || lv > prev, SKINRT_E_INVALID, "morph target indices must be strictly increasing");
+                prev = lv;
             }
+            const uint32_t v = sc.first_vertex + lv;
             float dl[9];
             for (int e = 0; e < 3; ++e) {
                 dl[e] = tg.position ? tg.position[(size_t)row * 3 + e] : 0.0f;
@@ -412,7 +519,10 @@ int compile_rig(const skinrt_rig_desc* desc, const skinrt_config* cfg, CompiledR
 
 void fill_rig_info(const CompiledRig& r, uint64_t device_bytes, skinrt_rig_info* info) {
     std::memset(info, 0, sizeof *info);
-    info->node_count = r.N; info->joint_count = r.J; info->vertex_count = r.V; info->set_count = r.K;
+    info->node_count = r.N;
+    info->joint_count = 0;  // joints of the skins; palette_count adds the un-skinned sections' entries
+    for (const SkinSpan& sk : r.skins) info->joint_count += sk.count;
+    info->vertex_count = r.V; info->set_count = r.K;
     info->target_count = r.M; info->clip_count = r.clips; info->level_count = r.levels;
     info->tile_count = r.T; info->tile_vertices = kTileVerts; info->max_tile_joints = r.max_tile_joints_any;
     info->lds_tiles = r.lds_tiles; info->max_channels = r.Cmax; info->morph_entries = r.morph_entries;
@@ -421,6 +531,9 @@ void fill_rig_info(const CompiledRig& r, uint64_t device_bytes, skinrt_rig_info*
     info->bind_extent = r.bind_extent;
     info->weight_channel_clips = r.weight_channel_clips;
     info->skip_weight_sets = r.skip_sets ? 1u : 0u;
+    info->skin_count = (uint32_t)r.skins.size();
+    info->section_count = (uint32_t)r.sections.size();
+    info->palette_count = r.J;
 }
 
 }  // namespace skinrt

@@ -51,8 +51,24 @@ constexpr uint32_t kMorphDenseMin = 57;       // touched vertices from which a p
 #endif
 constexpr uint32_t kMorphSlots = SKINRT_MORPH_SLOTS;  // LDS slots per wave: active pairs streamed per instance
 
+// who drives morph target m of an instance playing a given clip: a SKINRT_PATH_WEIGHTS channel, or nobody (chan < 0)
+struct WeightSrc {
+    int32_t chan;     // global channel index, or -1: the weight the host set
+    uint16_t first;   // first target of the channel's mesh section (component = m - first)
+    uint16_t width;   // targets of that section = floats per key of the channel
+};
+
+// a skin's joints inside the palette
+struct SkinSpan {
+    uint32_t first, count;
+};
+
 struct CompiledRig {
+    // J = palette entries: every skin's joints one skin after the other, then one entry per distinct node of an
+    // un-skinned section (joint = the node's world matrix, inverse bind = identity)
     uint32_t N = 0, J = 0, V = 0, K = 0, M = 0, clips = 0, Cmax = 0, levels = 0, T = 0;
+    std::vector<SkinSpan> skins;
+    std::vector<skinrt_section_layout> sections;
     uint32_t tangent_stride = 3;
     // skin-stage arithmetic chosen for this rig (skinrt_config.exact_arithmetic; 0 = by bind_extent)
     uint32_t exact = 0;
@@ -68,8 +84,9 @@ struct CompiledRig {
     std::vector<int32_t> node_chan;     // [clips][N][3] global channel index or -1
     std::vector<ChanRec> chans;
     std::vector<uint32_t> clip_chan_count;  // [clips]
-    std::vector<int32_t> clip_weights_chan; // [clips] global index of the clip's SKINRT_PATH_WEIGHTS channel, or -1
-    uint32_t weight_channel_clips = 0;      // clips that have one
+    std::vector<WeightSrc> weight_src;      // [clips][M]
+    uint32_t weight_channel_clips = 0;      // clips that carry at least one SKINRT_PATH_WEIGHTS channel
+    std::vector<float> clip_length;         // [clips] largest key time of the clip (AnimationChannelAsset.length, max over channels)
     std::vector<float> times, values;
     // skin
     std::vector<uint32_t> joint_node;   // [J]
@@ -97,7 +114,7 @@ struct CompiledRig {
     uint32_t max_tile_pairs = 0;
     uint64_t morph_entries = 0;         // nonzero (vertex, target) deltas kept
     // kept for skinrt_export_interleaved
-    std::vector<uint16_t> joints0;      // [V][4]
+    std::vector<uint16_t> joints0;      // [V][4] (indices into the vertex's own skin, as given; zeros for un-skinned sections)
     std::vector<float> weights0;        // [V][4]
 };
 

@@ -11,10 +11,11 @@ namespace {
 struct Walk {
     FlatRig& rig;
     std::map<AssetIndex, uint32_t> index_of;  // first occurrence wins (a node shared by two scenes is two copies)
-    struct MeshRef { uint32_t node; const NodeAsset* src; };
-    std::vector<MeshRef> skinned;
-    std::shared_ptr<const SkinAsset> skin;
+    struct MeshRef { uint32_t node; const NodeAsset* src; int32_t skin; };
+    std::vector<MeshRef> meshes;                           // every node whose mesh becomes a section, DFS order
+    std::vector<std::shared_ptr<const SkinAsset>> skins;   // distinct skins by id, in the order they are met
     const AssetIndex* wanted_skin;
+    bool include_unskinned;
 
     void node(const NodeAsset& n, int32_t parent) {
         const uint32_t me = rig.node_count();
@@ -33,9 +34,15 @@ struct Walk {
         rig.scale.insert(rig.scale.end(), trs.scale.begin(), trs.scale.end());
         rig.matrix.insert(rig.matrix.end(), m.begin(), m.end());
         rig.has_matrix.push_back(is_matrix);
-        if (n.skin && n.mesh) {
-            if (!skin && (!wanted_skin || n.skin->id == *wanted_skin)) skin = n.skin;
-            if (skin && n.skin->id == skin->id) skinned.push_back({me, &n});
+        if (n.mesh && n.skin) {  // node.rs:95-96: the node names its skin (shared by Arc, cached per glTF skin: loader/gltf/mod.rs:1124-1128)
+            if (!wanted_skin || n.skin->id == *wanted_skin) {
+                size_t k = 0;
+                while (k < skins.size() && !(skins[k]->id == n.skin->id)) ++k;
+                if (k == skins.size()) skins.push_back(n.skin);
+                meshes.push_back({me, &n, (int32_t)k});
+            }
+        } else if (n.mesh && !wanted_skin && include_unskinned) {
+            meshes.push_back({me, &n, -1});  // drawn with the node's world matrix as InstanceUniform (shader.wgsl:143-152)
         }
         for (const NodeAsset& c : n.children) node(c, (int32_t)me);
     }
@@ -71,7 +78,7 @@ int flatten(const std::vector<SceneAsset>& scenes, const std::vector<AnimationAs
             const FlattenOptions& opt, FlatRig& rig, std::string& err) {
     rig = FlatRig();
     if (opt.scene >= (int)scenes.size()) return fail(err, SKINRT_E_RANGE, "scene index out of range");
-    Walk w{rig, {}, {}, nullptr, opt.skin};
+    Walk w{rig, {}, {}, {}, opt.skin, opt.include_unskinned};
     for (size_t s = 0; s < scenes.size(); ++s) {
         if (opt.scene >= 0 && (size_t)opt.scene != s) continue;
         for (const NodeAsset& n : scenes[s].nodes) w.node(n, -1);
@@ -82,19 +89,22 @@ int flatten(const std::vector<SceneAsset>& scenes, const std::vector<AnimationAs
         rig.has_matrix.clear();
     }
 
-    // skin: joint -> node, inverse bind matrices (a8)
-    if (w.skin) {
-        for (const AssetIndex& j : w.skin->joint_ids) {
+    // skins: joint -> node, inverse bind matrices (a8)
+    for (const auto& sk : w.skins) {
+        FlatSkin fs;
+        fs.id = sk->id;
+        for (const AssetIndex& j : sk->joint_ids) {
             auto it = w.index_of.find(j);
             if (it == w.index_of.end()) return fail(err, SKINRT_E_RANGE, "skin joint id is not a node of the flattened scenes");
-            rig.joint_node.push_back(it->second);
+            fs.joint_node.push_back(it->second);
         }
-        const auto& ibm = w.skin->inverse_bind_matrices;
+        const auto& ibm = sk->inverse_bind_matrices;
         if (!ibm.empty()) {
-            if (ibm.size() != w.skin->joint_ids.size())
+            if (ibm.size() != sk->joint_ids.size())
                 return fail(err, SKINRT_E_INVALID, "inverse_bind_matrices length != joint_ids length");
-            for (const Mat4& m : ibm) rig.inverse_bind.insert(rig.inverse_bind.end(), m.begin(), m.end());
+            for (const Mat4& m : ibm) fs.inverse_bind.insert(fs.inverse_bind.end(), m.begin(), m.end());
         }
+        rig.skins.push_back(std::move(fs));
     }
 
     // clips (a1): one per AnimationAsset, channels in file order
@@ -119,33 +129,45 @@ int flatten(const std::vector<SceneAsset>& scenes, const std::vector<AnimationAs
         rig.clip_length.push_back(length);
     }
 
-    // mesh (a11, a13): primitives of the nodes that use the skin, concatenated
-    size_t K = 0, M = 0, prims = 0;
-    for (const auto& mr : w.skinned)
-        for (const PrimitiveAsset& p : mr.src->mesh->primitives) {
-            K = std::max(K, std::min(p.attributes.joints.size(), p.attributes.weights.size()));
-            M = std::max(M, p.targets.size());
-            ++prims;
-        }
+    // mesh (a11, a13): one section per mesh node, its primitives concatenated; the morph targets of a section are its
+    // MeshAsset's (every primitive of a glTF mesh carries the same number of targets, weights live on the mesh: mesh.rs:4-8)
+    size_t K = 0;
+    for (const auto& mr : w.meshes)
+        if (mr.skin >= 0)
+            for (const PrimitiveAsset& p : mr.src->mesh->primitives)
+                K = std::max(K, std::min(p.attributes.joints.size(), p.attributes.weights.size()));
     if (K > 4) return fail(err, SKINRT_E_LIMIT, "more than 4 joint/weight sets");
+    if (K == 0 && !w.meshes.empty()) K = 1;  // un-skinned meshes only: one (unread) set keeps the descriptor regular
     rig.joints.assign(K, {});
     rig.weights.assign(K, {});
-    rig.targets.assign(M, {});
-    for (FlatTarget& t : rig.targets) t.dense = prims == 1;
-    std::vector<bool> any_normal(M, false), any_tangent(M, false);
-    for (const auto& mr : w.skinned)
-        for (const PrimitiveAsset& p : mr.src->mesh->primitives)
+    for (const auto& mr : w.meshes) {
+        const MeshAsset& mesh = *mr.src->mesh;
+        size_t M = 0;
+        bool all_have_all = true;
+        for (const PrimitiveAsset& p : mesh.primitives) M = std::max(M, p.targets.size());
+        for (const PrimitiveAsset& p : mesh.primitives) all_have_all = all_have_all && p.targets.size() == M;
+        skinrt_section_desc sec{};
+        sec.node = mr.node;
+        sec.skin = mr.skin;
+        sec.first_vertex = rig.vertex_count();
+        sec.first_target = (uint32_t)rig.targets.size();
+        sec.target_count = (uint32_t)M;
+        const uint32_t section_index = (uint32_t)rig.sections.size();
+        rig.targets.resize(rig.targets.size() + M);
+        FlatTarget* tg = rig.targets.data() + sec.first_target;
+        for (size_t m = 0; m < M; ++m) tg[m].dense = all_have_all;  // every primitive brings its rows: the concatenation is dense
+        std::vector<bool> any_normal(M, false), any_tangent(M, false);
+        for (const PrimitiveAsset& p : mesh.primitives)
             for (size_t m = 0; m < p.targets.size(); ++m) {
                 any_normal[m] = any_normal[m] || !p.targets[m].normal.empty();
                 any_tangent[m] = any_tangent[m] || !p.targets[m].tangent.empty();
             }
-    for (const auto& mr : w.skinned) {
-        const MeshAsset& mesh = *mr.src->mesh;
         for (size_t pi = 0; pi < mesh.primitives.size(); ++pi) {
             const PrimitiveAsset& p = mesh.primitives[pi];
             const auto& at = p.attributes;
             const size_t n = at.position.size();
             const uint32_t first = rig.vertex_count();
+            const uint32_t local_first = first - sec.first_vertex;  // target rows and indices count from the section's first vertex
             if ((!at.normal.empty() && at.normal.size() != n) || (!at.tangent.empty() && at.tangent.size() != n))
                 return fail(err, SKINRT_E_INVALID, "primitive attribute lengths differ");
             for (size_t v = 0; v < n; ++v) {
@@ -158,7 +180,8 @@ int flatten(const std::vector<SceneAsset>& scenes, const std::vector<AnimationAs
                 rig.tangent.insert(rig.tangent.end(), tt.begin(), tt.end());
             }
             for (size_t k = 0; k < K; ++k) {
-                const bool have = k < at.joints.size() && k < at.weights.size();
+                // an un-skinned section's sets are not read by the library (skinrt.h): zeros
+                const bool have = mr.skin >= 0 && k < at.joints.size() && k < at.weights.size();
                 if (have && (at.joints[k].size() != n || at.weights[k].size() != n))
                     return fail(err, SKINRT_E_INVALID, "joint/weight set length differs from position length");
                 for (size_t v = 0; v < n; ++v) {
@@ -172,12 +195,12 @@ int flatten(const std::vector<SceneAsset>& scenes, const std::vector<AnimationAs
             }
             for (size_t m = 0; m < p.targets.size(); ++m) {
                 const PrimitiveAssetMorphTarget& src = p.targets[m];
-                FlatTarget& dst = rig.targets[m];
+                FlatTarget& dst = tg[m];
                 if (src.position.size() != n || (!src.normal.empty() && src.normal.size() != n) ||
                     (!src.tangent.empty() && src.tangent.size() != n))
                     return fail(err, SKINRT_E_INVALID, "morph target length differs from position length");
                 for (size_t v = 0; v < n; ++v) {
-                    if (!dst.dense) dst.indices.push_back(first + (uint32_t)v);
+                    if (!dst.dense) dst.indices.push_back(local_first + (uint32_t)v);
                     dst.position.insert(dst.position.end(), src.position[v].begin(), src.position[v].end());
                     if (any_normal[m]) {
                         const std::array<float, 3> z{0, 0, 0};
@@ -197,25 +220,26 @@ int flatten(const std::vector<SceneAsset>& scenes, const std::vector<AnimationAs
                     }
                 }
             }
-            rig.ranges.push_back({mr.node, (uint32_t)pi, first, (uint32_t)n});
+            rig.ranges.push_back({mr.node, (uint32_t)pi, first, (uint32_t)n, section_index});
         }
+        sec.vertex_count = rig.vertex_count() - sec.first_vertex;
+        // default weights (a13): node.weights if non-empty, else mesh.weights, else zeros
+        const std::vector<float>& src = !mr.src->weights.empty() ? mr.src->weights : mesh.weights;
+        rig.default_weights.resize(rig.targets.size(), 0.0f);
+        std::copy_n(src.begin(), std::min(src.size(), M), rig.default_weights.begin() + sec.first_target);
+        rig.sections.push_back(sec);
     }
-    // default weights (a13): node.weights if non-empty, else mesh.weights, else zeros
-    if (M && !w.skinned.empty()) {
-        const NodeAsset& n0 = *w.skinned.front().src;
-        const std::vector<float>& src = !n0.weights.empty() ? n0.weights : n0.mesh->weights;
-        rig.default_weights.assign(M, 0.0f);
-        std::copy_n(src.begin(), std::min(src.size(), M), rig.default_weights.begin());
-    }
-    // weights channels: the C ABI reads key_count x M (x 3) floats — check the width here, where the lengths are known.
-    // A channel aimed at a mesh node that is not part of the flattened skin is dropped (its mesh is not in the rig).
+    // weights channels: the C ABI reads key_count x M (x 3) floats, M = the targets of the section on the channel's node —
+    // check the width here, where the lengths are known.  A channel aimed at a node whose mesh is not in the rig (or has
+    // no targets) is dropped.
     for (auto& clip : rig.clips) {
         for (size_t k = 0; k < clip.size();) {
             FlatChannel& ch = clip[k];
             if (ch.path != SKINRT_PATH_WEIGHTS) { ++k; continue; }
-            const bool ours = std::any_of(w.skinned.begin(), w.skinned.end(), [&](const auto& sk) { return sk.node == ch.node; });
-            if (!ours || M == 0) { clip.erase(clip.begin() + (long)k); continue; }
-            const size_t per_key = (ch.interpolation == SKINRT_INTERP_CUBICSPLINE ? 3 : 1) * M;
+            auto sec = std::find_if(rig.sections.begin(), rig.sections.end(),
+                                    [&](const skinrt_section_desc& sc) { return sc.node == ch.node && sc.target_count; });
+            if (sec == rig.sections.end()) { clip.erase(clip.begin() + (long)k); continue; }
+            const size_t per_key = (ch.interpolation == SKINRT_INTERP_CUBICSPLINE ? 3 : 1) * (size_t)sec->target_count;
             if (ch.values.size() != ch.times.size() * per_key)
                 return fail(err, SKINRT_E_INVALID, "weights channel: values per key != morph target count of the mesh");
             ++k;
@@ -235,9 +259,22 @@ const skinrt_rig_desc* FlatRig::desc() {
     desc_.scale = ptr(scale);
     desc_.matrix = ptr(matrix);
     desc_.has_matrix = ptr(has_matrix);
-    desc_.joint_count = (uint32_t)joint_node.size();
-    desc_.joint_node = ptr(joint_node);
-    desc_.inverse_bind = ptr(inverse_bind);
+    if (skins.empty() && sections.empty()) {  // short form (one skin, one section)
+        desc_.joint_count = (uint32_t)joint_node.size();
+        desc_.joint_node = ptr(joint_node);
+        desc_.inverse_bind = ptr(inverse_bind);
+    } else {
+        skin_descs_.assign(skins.size(), {});
+        for (size_t k = 0; k < skins.size(); ++k) {
+            skin_descs_[k].joint_count = (uint32_t)skins[k].joint_node.size();
+            skin_descs_[k].joint_node = ptr(skins[k].joint_node);
+            skin_descs_[k].inverse_bind = ptr(skins[k].inverse_bind);
+        }
+        desc_.skin_count = (uint32_t)skins.size();
+        desc_.skins = ptr(skin_descs_);
+        desc_.section_count = (uint32_t)sections.size();
+        desc_.sections = ptr(sections);
+    }
     clip_descs_.assign(clips.size(), {});
     channel_descs_.assign(clips.size(), {});
     for (size_t c = 0; c < clips.size(); ++c) {

@@ -16,7 +16,10 @@ using namespace renderer_asset;
 
 struct FlattenOptions {
     int scene = -1;                 // -1: every scene in order; else only scenes[scene]
-    const AssetIndex* skin = nullptr;  // which skin's primitives form the mesh; null: first skin met in DFS order
+    // null: EVERY node with a mesh becomes a section — all skins of the scenes (an avatar usually has several over one
+    // node tree: body / face / hair) and the un-skinned meshes; else only the meshes that use this skin
+    const AssetIndex* skin = nullptr;
+    bool include_unskinned = true;  // with skin == null: meshes on nodes without a skin become un-skinned sections
 };
 
 // a primitive's vertices inside the rig's concatenated vertex arrays
@@ -24,6 +27,14 @@ struct PrimitiveRange {
     uint32_t node;        // flat node index of the mesh node
     uint32_t primitive;   // index in MeshAsset::primitives
     uint32_t first_vertex, vertex_count;
+    uint32_t section;     // index in FlatRig::sections
+};
+
+// One SkinAsset (skin.rs:5-11) over the flat nodes
+struct FlatSkin {
+    AssetIndex id;
+    std::vector<uint32_t> joint_node;
+    std::vector<float> inverse_bind;  // empty = identity
 };
 
 struct FlatChannel {
@@ -44,13 +55,18 @@ struct FlatRig {
     std::vector<int32_t> parent;
     std::vector<float> translation, rotation, scale, matrix;
     std::vector<uint8_t> has_matrix;
-    // skin
+    // skins in the order the DFS meets them, and the mesh sections (skinrt_section_desc: node, skin or -1, vertex and
+    // target ranges).  Loaders that produce one skinned mesh (PMX) may instead fill the short form below and leave
+    // both empty.
+    std::vector<FlatSkin> skins;
+    std::vector<skinrt_section_desc> sections;
+    // short form: one skin, one section
     std::vector<uint32_t> joint_node;
     std::vector<float> inverse_bind;  // empty = identity
     // clips (one per AnimationAsset, channels in file order)
     std::vector<std::vector<FlatChannel>> clips;
     std::vector<float> clip_length;   // max over channels of AnimationChannelAsset::length
-    // mesh: primitives of every node that uses the skin, concatenated in DFS order
+    // mesh: primitives of every mesh node, concatenated in DFS order (a section = one node's primitives)
     std::vector<float> position, normal, tangent;  // tangent stride 4
     std::vector<std::vector<uint16_t>> joints;     // K x [V][4]
     std::vector<std::vector<float>> weights;       // K x [V][4]
@@ -72,6 +88,7 @@ private:
     std::vector<skinrt_morph_target_desc> target_descs_;
     std::vector<const uint16_t*> joint_ptrs_;
     std::vector<const float*> weight_ptrs_;
+    std::vector<skinrt_skin_desc> skin_descs_;
 };
 
 // Returns SKINRT_OK or a negative SKINRT_E_* (never throws / aborts; the reference panics on the

@@ -114,8 +114,10 @@ static void host_checks() {
     EXPECT(rig.matrix[4 * 16 + 12] == 9.0f);
     EXPECT(rig.rotation[1 * 4 + 2] == 1.0f && rig.rotation[1 * 4 + 3] == 0.0f);
     // joints resolve through the id map, not by glTF index
-    EXPECT(rig.joint_node.size() == 3 && rig.joint_node[0] == 2 && rig.joint_node[1] == 3 && rig.joint_node[2] == 0);
-    EXPECT(rig.inverse_bind.size() == 48 && rig.inverse_bind[13] == -3.0f);
+    EXPECT(rig.skins.size() == 1 && rig.sections.size() == 1 && rig.sections[0].skin == 0 && rig.sections[0].node == 3);
+    const FlatSkin& sk0 = rig.skins[0];
+    EXPECT(sk0.joint_node.size() == 3 && sk0.joint_node[0] == 2 && sk0.joint_node[1] == 3 && sk0.joint_node[2] == 0);
+    EXPECT(sk0.inverse_bind.size() == 48 && sk0.inverse_bind[13] == -3.0f);
     // clips
     EXPECT(rig.clips.size() == 1 && rig.clips[0].size() == 2 && rig.clip_length[0] == 2.0f);
     EXPECT(rig.clips[0][0].node == 2 && rig.clips[0][0].path == SKINRT_PATH_TRANSLATION && rig.clips[0][0].interpolation == SKINRT_INTERP_LINEAR);
@@ -161,6 +163,93 @@ static void host_checks() {
         FlatRig r2;
         EXPECT(flatten(scenes, anims, o, r2, err) == SKINRT_E_RANGE);
     }
+}
+
+// scene of build() + a second skin on the same node tree (node F(4) under B, joints D and A, its own morph target and a
+// weights channel) + an un-skinned mesh on the Matrix node E: what an avatar with several skins and a prop looks like
+static void build_multi(std::vector<SceneAsset>& scenes, std::vector<AnimationAsset>& anims) {
+    build(scenes, anims);
+    auto skin1 = std::make_shared<SkinAsset>();
+    skin1->id = AssetIndex::type_index(kBundle, BundleAssetType::Skin, 1);
+    skin1->joint_ids = {node_id(5), node_id(7)};  // no inverse bind matrices: identity (loader/gltf/mod.rs:1139-1145)
+    NodeAsset F = make_node(4, {0, 0, 0});
+    F.skin = skin1;
+    MeshAsset face;
+    face.weights = {0.75f};
+    PrimitiveAsset fp;
+    fp.attributes.position = {{1, 1, 1}, {2, 0, 0}};
+    fp.attributes.normal = {{0, 1, 0}, {1, 0, 0}};
+    fp.attributes.tangent = {{1, 0, 0, 1}, {0, 1, 0, 1}};
+    fp.attributes.joints = {{{1, 0, 0, 0}, {0, 1, 0, 0}}};
+    fp.attributes.weights = {{{1, 0, 0, 0}, {0.25f, 0.75f, 0, 0}}};
+    fp.targets.resize(1);
+    fp.targets[0].position = {{0, 0, 4}, {0, 0, 0}};
+    face.primitives = {fp};
+    F.mesh = face;
+    NodeAsset& A = scenes[0].nodes[0];
+    A.children[0].children.push_back(F);  // A -> B -> [D, F]
+    NodeAsset& E = scenes[0].nodes[1];
+    MeshAsset prop;
+    PrimitiveAsset pp;
+    pp.attributes.position = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    pp.attributes.normal = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    pp.attributes.tangent = {{0, 1, 0, 1}, {0, 0, 1, 1}, {1, 0, 0, 1}};
+    prop.primitives = {pp};
+    E.mesh = prop;
+    {
+        AnimationChannelAsset c;  // F's mesh: its one morph weight goes 0 -> 1 over 2 s
+        c.sampler.kind = AnimationSampler::Kind::MorphTargetWeights;
+        c.sampler.weights.kind = AnimationKeyFrames<std::vector<float>>::Kind::Linear;
+        c.sampler.weights.frames = {{0.0f, {0.0f}}, {2.0f, {1.0f}}};
+        c.length = 2.0f;
+        c.target_id = node_id(4);
+        anims[0].channels.push_back(c);
+    }
+}
+
+static void host_checks_multi() {
+    std::vector<SceneAsset> scenes;
+    std::vector<AnimationAsset> anims;
+    build_multi(scenes, anims);
+    FlatRig rig;
+    std::string err;
+    EXPECT(flatten(scenes, anims, {}, rig, err) == SKINRT_OK);
+    // DFS pre-order A B D F C E; sections in that order: F (skin 1 is met first), C, E
+    EXPECT(rig.node_count() == 6 && rig.node_id[3].index == 4 && rig.node_id[4].index == 0);
+    EXPECT(rig.skins.size() == 2 && rig.skins[0].id.index == 1 && rig.skins[1].id.index == 0);
+    EXPECT(rig.skins[0].joint_node.size() == 2 && rig.skins[0].joint_node[0] == 0 && rig.skins[0].joint_node[1] == 2 && rig.skins[0].inverse_bind.empty());
+    EXPECT(rig.sections.size() == 3);
+    if (rig.sections.size() == 3) {
+        EXPECT(rig.sections[0].node == 3 && rig.sections[0].skin == 0 && rig.sections[0].first_vertex == 0 && rig.sections[0].vertex_count == 2);
+        EXPECT(rig.sections[0].first_target == 0 && rig.sections[0].target_count == 1);
+        EXPECT(rig.sections[1].node == 4 && rig.sections[1].skin == 1 && rig.sections[1].first_vertex == 2 && rig.sections[1].vertex_count == 5);
+        EXPECT(rig.sections[1].first_target == 1 && rig.sections[1].target_count == 2);
+        EXPECT(rig.sections[2].node == 5 && rig.sections[2].skin == -1 && rig.sections[2].first_vertex == 7 && rig.sections[2].vertex_count == 3);
+        EXPECT(rig.sections[2].target_count == 0);
+    }
+    EXPECT(rig.vertex_count() == 10 && rig.targets.size() == 3 && rig.targets[0].dense && !rig.targets[1].dense);
+    EXPECT(rig.targets[2].indices.size() == 2 && rig.targets[2].indices[0] == 3);  // counted from the section's first vertex
+    EXPECT(rig.default_weights.size() == 3 && rig.default_weights[0] == 0.75f && rig.default_weights[2] == 0.25f);
+    EXPECT(rig.clips[0].size() == 3 && rig.clips[0][2].path == SKINRT_PATH_WEIGHTS && rig.clips[0][2].node == 3);
+    skinrt_rig_info info{};
+    const int rc = skinrt_validate_rig(nullptr, rig.desc(), &info);
+    if (rc != SKINRT_OK) std::printf("validate: %s\n", skinrt_last_error());
+    EXPECT(rc == SKINRT_OK);
+    EXPECT(info.skin_count == 2 && info.section_count == 3 && info.joint_count == 5 && info.palette_count == 6 && info.vertex_count == 10);
+    EXPECT(info.weight_channel_clips == 1);
+    // the one-skin view of the same scenes: only that skin's meshes
+    FlattenOptions o;
+    const AssetIndex want = AssetIndex::type_index(kBundle, BundleAssetType::Skin, 0);
+    o.skin = &want;
+    FlatRig r1;
+    EXPECT(flatten(scenes, anims, o, r1, err) == SKINRT_OK);
+    EXPECT(r1.skins.size() == 1 && r1.sections.size() == 1 && r1.vertex_count() == 5 && r1.clips[0].size() == 2);
+    // un-skinned meshes can be left out
+    FlattenOptions o2;
+    o2.include_unskinned = false;
+    FlatRig r2;
+    EXPECT(flatten(scenes, anims, o2, r2, err) == SKINRT_OK);
+    EXPECT(r2.sections.size() == 2 && r2.vertex_count() == 7);
 }
 
 // ---- direct evaluation of the owned tree (test-only) -------------------------------------------
@@ -245,11 +334,47 @@ static void gpu_checks() {
     EXPECT(std::fabs(verts[3].position[0] - 6.0f) < 1e-6);
 }
 
+static void gpu_checks_multi() {
+    std::vector<SceneAsset> scenes;
+    std::vector<AnimationAsset> anims;
+    build_multi(scenes, anims);
+    SkinnedScene scene(scenes, anims, 2);
+    const float tau[2] = {0.0f, 1.0f};
+    const uint32_t clip[2] = {0, 0};
+    scene.set_clocks(tau, clip);
+    scene.render();
+    scene.synchronize();
+    const auto pos = scene.download<float>(skinrt_get_positions);  // [2][10][3]
+    EXPECT(pos.size() == 2 * 10 * 3);
+    // section F, vertex 0: joint 1 of skin 1 = node D, no inverse bind: world(D) * p.  D's world at tau: A(1,0,0) * B(0,2,0; half turn
+    // about Z) * D(0,1+tau,0) -> origin (1, 2 - (1+tau), 0), axes x,y flipped.  p = (1,1,1) + w * (0,0,4), w = tau / 2 from the channel
+    for (int i = 0; i < 2; ++i) {
+        const float w = tau[i] * 0.5f, ty = 2.0f - (1.0f + tau[i]);
+        EXPECT(std::fabs(pos[(i * 10 + 0) * 3 + 0] - (1.0f - 1.0f)) < 1e-6);
+        EXPECT(std::fabs(pos[(i * 10 + 0) * 3 + 1] - (ty - 1.0f)) < 1e-6);
+        EXPECT(std::fabs(pos[(i * 10 + 0) * 3 + 2] - (1.0f + 4.0f * w)) < 1e-6);
+    }
+    // the prop on E: world(E) = diag(2) + translation (9,0,0): vertex (0,1,0) -> (9,2,0); normal matrix = diag(0.5)
+    const auto nrm = scene.download<float>(skinrt_get_normals);
+    EXPECT(std::fabs(pos[(1 * 10 + 8) * 3 + 0] - 9.0f) < 1e-6 && std::fabs(pos[(1 * 10 + 8) * 3 + 1] - 2.0f) < 1e-6);
+    EXPECT(std::fabs(nrm[(1 * 10 + 8) * 3 + 1] - 0.5f) < 1e-6);
+    const InstanceUniform iu = scene.instance_uniform(1, 5);
+    EXPECT(iu.transform[0][0] == 2.0f && iu.transform[3][0] == 9.0f && iu.transform[3][3] == 1.0f && iu.normal[1][1] == 0.5f && iu.normal[1][3] == 0.0f);
+    // per-skin palettes: skin 0 (the face's) has 2 joints, skin 1 (the body's) 3
+    const auto u0 = scene.skin_uniform(1, 0), u1 = scene.skin_uniform(1, 1);
+    EXPECT(u0[1].transform[3][1] == 0.0f - 0.0f + (2.0f - 2.0f) && u0[2].transform[0][0] == 0.0f && u1[2].transform[0][0] == 1.0f && u1[3].transform[0][0] == 0.0f);
+    const auto fv = scene.texture_skin_vertices_of(0, 1);
+    EXPECT(fv.size() == 2 && fv[1].joint_index[1] == 1 && fv[1].joint_weight[1] == 0.75f);
+    EXPECT(std::fabs(fv[0].position[2] - 3.0f) < 1e-6);
+}
+
 int main(int argc, char** argv) {
     host_checks();
+    host_checks_multi();
     if (argc > 1 && std::string(argv[1]) == "--gpu") {
         try {
             gpu_checks();
+            gpu_checks_multi();
         } catch (const Error& e) {
             std::printf("FAIL %s\n", e.what());
             ++failures;

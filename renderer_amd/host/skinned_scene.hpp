@@ -3,6 +3,7 @@
 // the two reference objects that consume the path's output:
 //   SkinMatrix / SkinUniformBuffer   renderer/src/renderer/uniform/skin.rs:12-23,59-71
 //   ColorSkinVertex / TextureSkinVertex  renderer/src/renderer/buffer/vertex.rs:60-102
+//   InstanceUniform / InstanceUniformBuffer  renderer/src/renderer/uniform/transform.rs:8-20,51-59
 // SkinnedScene::render() is what Entity::render (renderer/src/client/entity/mod.rs:34) would
 // call once per frame for an asset-backed entity.
 #pragma once
@@ -32,6 +33,15 @@ struct SkinMatrix {        // uniform/skin.rs:12-17, 112 bytes
     float normal[3][4];    // inverse-transpose columns, w = 0
 };
 static_assert(sizeof(SkinMatrix) == 112, "SkinMatrix layout");
+
+#pragma pack(push, 1)
+struct InstanceUniform {   // uniform/transform.rs:8-14, 124 bytes
+    float transform[4][4]; // column-major
+    float normal[3][4];    // inverse-transpose columns, w = 0
+    uint8_t padding[12];
+};
+#pragma pack(pop)
+static_assert(sizeof(InstanceUniform) == SKINRT_INSTANCE_UNIFORM_BYTES, "InstanceUniform layout");
 
 struct ColorSkinVertex {   // buffer/vertex.rs:60-69, 76 bytes
     float position[3], color[4], normal[3], tangent[3];
@@ -81,10 +91,22 @@ public:
     void render(uint32_t stages = SKINRT_STAGE_ALL) { check(skinrt_evaluate(crowd_, stages)); }
     void synchronize() { check(skinrt_synchronize(ctx_)); }
 
-    // SkinUniformBuffer::update for one instance: 128 SkinMatrix entries, unused ones zero
-    std::vector<SkinMatrix> skin_uniform(uint32_t instance) {
+    // SkinUniformBuffer::update for one instance and one of the scene's skins: 128 SkinMatrix entries, unused ones zero
+    std::vector<SkinMatrix> skin_uniform(uint32_t instance, uint32_t skin = 0) {
         std::vector<SkinMatrix> out(MAX_JOINTS);
-        check(skinrt_export_skin_uniform(crowd_, instance, out.data()));
+        check(skinrt_export_skin_uniform_of(crowd_, skin, instance, out.data()));
+        return out;
+    }
+    // InstanceUniformBuffer::update for a node that carries an un-skinned mesh (or any other node)
+    InstanceUniform instance_uniform(uint32_t instance, uint32_t node) {
+        InstanceUniform out;
+        check(skinrt_export_instance_uniform(crowd_, instance, node, &out));
+        return out;
+    }
+    // one mesh node's vertices (FlatRig::sections) in the layout VertexBuffer::new takes for a skinned draw
+    std::vector<TextureSkinVertex> texture_skin_vertices_of(uint32_t section, uint32_t instance, const float* tex_coords = nullptr) {
+        std::vector<TextureSkinVertex> out(flat_.sections.at(section).vertex_count);
+        check(skinrt_export_interleaved_section(crowd_, section, instance, SKINRT_LAYOUT_TEXTURE_SKIN, tex_coords, out.data()));
         return out;
     }
     std::vector<TextureSkinVertex> texture_skin_vertices(uint32_t instance, const float* tex_coords = nullptr) {

@@ -11,7 +11,7 @@ from typing import List, Tuple
 import numpy as np
 
 from . import abi
-from .abi import Channel, MorphTarget, RigData, RigDesc
+from .abi import Channel, MorphTarget, RigData, RigDesc, Section, Skin
 
 _HOST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host")
 _PATH = os.path.join(_HOST, "build", "libskinrt_host.so")
@@ -65,13 +65,27 @@ def _np(ptr, shape, dtype):
 def _rig_from_desc(d: RigDesc) -> RigData:
     n, j, v = d.node_count, d.joint_count, d.vertex_count
     ts = d.tangent_stride
+    skins = sections = None
+    if d.skin_count or d.section_count:  # the flattener's form: every skin and every mesh node of the scenes
+        skins = []
+        for k in range(d.skin_count):
+            sk = d.skins[k]
+            skins.append(Skin(_np(sk.joint_node, (sk.joint_count,), np.uint32),
+                              _np(sk.inverse_bind, (sk.joint_count, 16), np.float32) if sk.inverse_bind else None))
+        sections = [Section(sc.node, sc.skin, sc.first_vertex, sc.vertex_count, sc.first_target, sc.target_count)
+                    for sc in (d.sections[k] for k in range(d.section_count))]
+
+    def weights_width(node):
+        if sections is None:
+            return d.target_count
+        return next(sc.target_count for sc in sections if sc.node == node and sc.target_count)
     clips: List[List[Channel]] = []
     for c in range(d.clip_count):
         cl = d.clips[c]
         chans = []
         for k in range(cl.channel_count):
             ch = cl.channels[k]
-            w = d.target_count if ch.path == abi.PATH_WEIGHTS else (4 if ch.path == abi.PATH_ROTATION else 3)
+            w = weights_width(ch.target_node) if ch.path == abi.PATH_WEIGHTS else (4 if ch.path == abi.PATH_ROTATION else 3)
             w *= 3 if ch.interpolation == abi.INTERP_CUBICSPLINE else 1
             chans.append(Channel(ch.target_node, ch.path, ch.interpolation, _np(ch.times, (ch.key_count,), np.float32),
                                  _np(ch.values, (ch.key_count, w), np.float32)))
@@ -87,8 +101,11 @@ def _rig_from_desc(d: RigDesc) -> RigData:
                    rotation=_np(d.rotation, (n, 4), np.float32), scale=_np(d.scale, (n, 3), np.float32),
                    matrix=_np(d.matrix, (n, 16), np.float32) if d.matrix else None,
                    has_matrix=_np(d.has_matrix, (n,), np.uint8) if d.has_matrix else None,
-                   joint_node=_np(d.joint_node, (j,), np.uint32),
-                   inverse_bind=_np(d.inverse_bind, (j, 16), np.float32) if d.inverse_bind else None,
+                   # with skins[] the short-form fields are unused; they mirror skin 0 for callers that look at one skin
+                   joint_node=_np(d.joint_node, (j,), np.uint32) if skins is None else (skins[0].joint_node if skins else np.zeros(0, np.uint32)),
+                   inverse_bind=(_np(d.inverse_bind, (j, 16), np.float32) if d.inverse_bind else None) if skins is None
+                   else (skins[0].inverse_bind if skins else None),
+                   skins=skins, sections=sections,
                    position=_np(d.position, (v, 3), np.float32), normal=_np(d.normal, (v, 3), np.float32),
                    tangent=_np(d.tangent, (v, ts), np.float32),
                    joints=[_np(d.joints[k], (v, 4), np.uint16) for k in range(d.set_count)],

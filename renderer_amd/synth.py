@@ -345,3 +345,100 @@ def tiny_spec(seed: int = 7, **kw) -> SynthSpec:
     base = SynthSpec("tiny", seed, nodes=10, joints=8, verts=64, sets=1, targets=3, clips=2, keys=3,
                      max_depth=4, frac_step=0.2, frac_cubic=0.3, instances=5)
     return scaled(base, **kw)
+
+
+def make_multi_rig(base: RigData, seed: int = 11, fractions=(0.5, 0.3, 0.2), rigid_frac: float = 0.06, rigid_sections: int = 1):
+    """An avatar-shaped rig with SEVERAL skins on one node tree plus un-skinned props, cut out of a one-skin rig: the
+    vertices are dealt to len(fractions) skinned sections (body / face / hair ...) and `rigid_sections` un-skinned ones.
+    Each skinned section gets a skin of its own — the joints its vertices use plus a few shared ones, in an order of its
+    own, so equal joints sit at different indices in different skins — and its vertex joint indices are rewritten to that
+    skin.  Every base morph target becomes one target per section it touches; a base `weights` channel becomes one
+    channel per morphed section (on that section's node).
+
+    Returns (rig, target_map): target_map[t] = the base target behind target t, so a base crowd's weights carry over as
+    mw[:, target_map].  Skinned sections then reproduce the base rig's results bit for bit (same joint matrices, same
+    weights, same target order) — a check that needs no oracle; un-skinned sections follow shader.wgsl:143-152."""
+    from .abi import Section, Skin
+    rng = _rng(seed, 9)
+    V, J, N = base.vertex_count, base.joint_count, base.node_count
+    K = base.set_count
+    n_rigid = int(V * rigid_frac) if rigid_sections else 0
+    n_skinned = V - n_rigid
+    cuts = [0]
+    for f in fractions[:-1]:
+        cuts.append(min(n_skinned, cuts[-1] + max(1, int(n_skinned * f))))
+    cuts.append(n_skinned)
+    for r in range(rigid_sections):
+        cuts.append(n_skinned + (n_rigid * (r + 1)) // rigid_sections)
+    n_sk = len(fractions)
+    # one mesh per node: distinct nodes for the sections; skinned ones prefer non-joint nodes, props hang off joints (they move)
+    joint_nodes = [int(x) for x in base.joint_node]
+    free = [n for n in range(N) if n not in set(joint_nodes)] + joint_nodes
+    nodes = free[:n_sk] + [joint_nodes[(3 + 5 * r) % J] for r in range(rigid_sections)]
+    if len(set(nodes)) != len(nodes):
+        nodes = list(dict.fromkeys(nodes + list(range(N))))[: n_sk + rigid_sections]
+    joints = [a.copy() for a in base.joints]
+    weights = [a.copy() for a in base.weights]
+    skins, sections = [], []
+    for s in range(n_sk + rigid_sections):
+        v0, v1 = cuts[s], cuts[s + 1]
+        if s < n_sk:
+            used = np.unique(np.concatenate([joints[k][v0:v1].reshape(-1) for k in range(K)])) if v1 > v0 else np.zeros(0, np.int64)
+            extra = rng.integers(0, J, size=min(J, 3))
+            order = rng.permutation(np.unique(np.concatenate([used.astype(np.int64), extra])))
+            local = np.full(J, 0xFFFF, np.int64)
+            local[order] = np.arange(order.shape[0])
+            for k in range(K):
+                joints[k][v0:v1] = local[joints[k][v0:v1].astype(np.int64)].astype(np.uint16)
+            skins.append(Skin(base.joint_node[order].copy(), None if base.inverse_bind is None else base.inverse_bind[order].copy()))
+            sections.append(Section(nodes[s], s, v0, v1 - v0))
+        else:
+            for k in range(K):  # not read for an un-skinned section: poison them
+                joints[k][v0:v1] = 0xFFFF
+                weights[k][v0:v1] = np.float32(np.nan)
+            sections.append(Section(nodes[s], -1, v0, v1 - v0))
+    # morph targets: one per (section, base target that touches the section), base order inside a section
+    targets, target_map = [], []
+    for sc in sections:
+        sc.first_target = len(targets)
+        v0, v1 = sc.first_vertex, sc.first_vertex + sc.vertex_count
+        for m, t in enumerate(base.targets):
+            if t.indices is None:
+                sl = slice(v0, v1)
+                parts = [a[sl] for a in (t.position, t.normal, t.tangent) if a is not None]
+                if not any(p.any() for p in parts):
+                    continue
+                targets.append(MorphTarget(position=None if t.position is None else t.position[sl].copy(),
+                                           normal=None if t.normal is None else t.normal[sl].copy(),
+                                           tangent=None if t.tangent is None else t.tangent[sl].copy()))
+            else:
+                sel = (t.indices >= v0) & (t.indices < v1)
+                if not sel.any():
+                    continue
+                targets.append(MorphTarget(position=None if t.position is None else t.position[sel].copy(),
+                                           normal=None if t.normal is None else t.normal[sel].copy(),
+                                           tangent=None if t.tangent is None else t.tangent[sel].copy(),
+                                           indices=(t.indices[sel] - v0).astype(np.uint32)))
+            target_map.append(m)
+        sc.target_count = len(targets) - sc.first_target
+    target_map = np.array(target_map, np.int64)
+    clips = []
+    for clip in base.clips:
+        out = []
+        for ch in clip:
+            if ch.path != PATH_WEIGHTS:
+                out.append(ch)
+                continue
+            for sc in sections:
+                if not sc.target_count:
+                    continue
+                cols = target_map[sc.first_target:sc.first_target + sc.target_count]
+                out.append(Channel(sc.node, PATH_WEIGHTS, ch.interpolation, ch.times.copy(),
+                                   np.ascontiguousarray(ch.values.reshape(ch.times.shape[0], -1, base.target_count)[..., cols])))
+        clips.append(out)
+    dw = None if base.default_weights is None or not len(target_map) else base.default_weights[target_map].copy()
+    rig = RigData(parent=base.parent, translation=base.translation, rotation=base.rotation, scale=base.scale,
+                  joint_node=skins[0].joint_node, inverse_bind=skins[0].inverse_bind, matrix=base.matrix, has_matrix=base.has_matrix,
+                  position=base.position, normal=base.normal, tangent=base.tangent, joints=joints, weights=weights,
+                  clips=clips, targets=targets, default_weights=dw, name=base.name + "-multi", skins=skins, sections=sections)
+    return rig, target_map

@@ -279,3 +279,95 @@ def test_graft_entry_build_checks_the_headers_version():
     (a stale literal failed the step for a whole round without any test noticing)."""
     src = open(os.path.join(os.path.dirname(HEADER), "..", "__graft_entry__.py")).read()
     assert "SKINRT_ABI_VERSION" in src and not re.search(r"skinrt_abi_version\(\)\s*==\s*\d", src)
+
+
+# ---- several skins / mesh sections (ABI 6) -------------------------------------------------------------------------
+
+def multi():
+    spec = synth.tiny_spec(seed=5, verts=700, joints=12, nodes=20, targets=6, weight_channels=1)
+    base = synth.make_rig(spec)
+    rig, tmap = synth.make_multi_rig(base)
+    return base, rig, tmap
+
+
+def test_multi_skin_rig_compiles_and_reports_its_layout():
+    base, rig, tmap = multi()
+    info = api.validate_rig(rig)
+    assert (info.skin_count, info.section_count) == (3, 4)
+    assert info.joint_count == rig.joint_count == sum(sk.joint_node.shape[0] for sk in rig.skins)
+    assert info.palette_count == rig.joint_count + 1            # one entry for the un-skinned section's node
+    assert info.target_count == len(tmap) and info.vertex_count == base.vertex_count
+    assert info.weight_channel_clips == 1
+    one = api.validate_rig(base)
+    assert (one.skin_count, one.section_count, one.palette_count) == (1, 1, base.joint_count)
+
+
+def test_sections_must_tile_vertices_and_targets():
+    _, rig, _ = multi()
+    rig.sections[1].first_vertex += 1
+    expect(rig, abi.E_INVALID, "tile the vertices")
+    _, rig, _ = multi()
+    rig.sections[-1].vertex_count -= 1
+    expect(rig, abi.E_INVALID, "cover every vertex")
+    _, rig, _ = multi()
+    rig.sections[0].target_count += 1
+    expect(rig, abi.E_INVALID, "tile the morph targets")
+
+
+def test_section_skin_and_node_are_range_checked():
+    _, rig, _ = multi()
+    rig.sections[0].skin = 3
+    expect(rig, abi.E_RANGE, "section skin out of range")
+    _, rig, _ = multi()
+    rig.sections[2].node = rig.node_count
+    expect(rig, abi.E_RANGE, "section node out of range")
+
+
+def test_joint_indices_are_checked_against_the_vertex_own_skin():
+    _, rig, _ = multi()
+    sc = rig.sections[1]
+    own = rig.skins[sc.skin].joint_node.shape[0]
+    assert own < rig.joint_count
+    rig.joints[0][sc.first_vertex, 0] = own   # a valid index of the whole palette, but not of this section's skin
+    rig.weights[0][sc.first_vertex, 0] = 0.5
+    expect(rig, abi.E_RANGE, "joint index out of range")
+
+
+def test_unskinned_sections_do_not_read_joints_or_weights():
+    _, rig, _ = multi()
+    sc = rig.sections[-1]
+    assert sc.skin == -1 and np.isnan(rig.weights[0][sc.first_vertex]).all() and (rig.joints[0][sc.first_vertex] == 0xFFFF).all()
+    api.validate_rig(rig)  # the poisoned sets of the prop are never looked at
+
+
+def test_weights_channel_must_sit_on_a_morphed_section_node():
+    _, rig, _ = multi()
+    used = {s.node for s in rig.sections}
+    other = next(n for n in range(rig.node_count) if n not in used)
+    w = next(ch for ch in rig.clips[0] if ch.path == abi.PATH_WEIGHTS)
+    w.target_node = other
+    expect(rig, abi.E_INVALID, "without a morphed mesh section")
+    _, rig, _ = multi()
+    w = next(ch for ch in rig.clips[0] if ch.path == abi.PATH_WEIGHTS)
+    rig.clips[0].append(abi.Channel(w.target_node, abi.PATH_WEIGHTS, abi.INTERP_STEP, w.times.copy(), w.values.copy()))
+    expect(rig, abi.E_INVALID, "two weights channels")
+
+
+def test_dense_target_of_a_section_has_the_sections_length():
+    _, rig, _ = multi()
+    t = next(t for t in rig.targets if t.indices is None)
+    t.position = np.concatenate([t.position, np.zeros((1, 3), np.float32)])
+    d = rig.to_desc()
+    # RigData sizes dense targets by their section; hand the library a wrong count directly
+    k = [i for i, x in enumerate(rig.targets) if x is t][0]
+    d.targets[k].count += 1
+    info = abi.RigInfo()
+    rc = api.load_library().skinrt_validate_rig(None, C.byref(d), C.byref(info))
+    assert rc == abi.E_INVALID and b"dense morph target" in api.load_library().skinrt_last_error()
+
+
+def test_shipped_library_is_not_a_measurement_build():
+    """skinrt_build_flags() is 0 for the product: no ablation / experiment switch compiled in (they make results wrong by
+    design), default tuning.  skinrt_init refuses anything else unless the config opts in."""
+    assert api.load_library().skinrt_build_flags() == 0
+    assert api.make_config().allow_experimental_build == 0

@@ -1,0 +1,204 @@
+"""Rigs with several skins on one node tree and un-skinned meshes (ABI 6) on the GPU, against the oracle.
+
+The reference attaches a skin per node (renderer-asset/src/node.rs:95; skins cached per glTF skin index,
+loader/gltf/mod.rs:1124-1166) and draws meshes on nodes without a skin with the node's world matrix as
+InstanceUniform (renderer/src/renderer/uniform/transform.rs:8-59, shader.wgsl:143-152).  The rigs here are cut out
+of one-skin rigs by synth.make_multi_rig, so every skinned section must ALSO reproduce the one-skin rig's results
+bit for bit — a check that does not go through the oracle at all.
+"""
+import numpy as np
+import pytest
+
+from renderer_amd import abi, api, synth
+from tests.helpers import DeviceBuffers, assert_close, assert_equal, run_gpu, run_oracle
+from tests.test_gpu_parity import _check_all
+
+pytestmark = pytest.mark.gpu
+
+
+def _avatar(seed=5, **kw):
+    spec = synth.tiny_spec(seed=seed, verts=1500, joints=14, nodes=22, targets=6, weight_channels=2, clips=3, keys=5, **kw)
+    base = synth.make_rig(spec)
+    rig, tmap = synth.make_multi_rig(base, seed=seed)
+    return spec, base, rig, tmap
+
+
+def _multi_crowd(spec, base, tmap, instances, with_root=False):
+    crowd = synth.make_crowd(spec, base, instances=instances, with_root=with_root)
+    multi = synth.CrowdState(crowd.tau, crowd.clip_id, None if crowd.morph_weights is None else crowd.morph_weights[:, tmap], crowd.root)
+    return crowd, multi
+
+
+@pytest.mark.parametrize("sets", [1, 2])
+@pytest.mark.parametrize("pose_path", [1, 2])
+@pytest.mark.parametrize("exact", [1, 0])
+def test_three_skins_and_a_prop_against_the_oracle(oracle32, exact, pose_path, sets):
+    spec, base, rig, tmap = _avatar(sets=sets)
+    assert [s.skin for s in rig.sections] == [0, 1, 2, -1] and rig.palette_count == rig.joint_count + 1
+    crowd, multi = _multi_crowd(spec, base, tmap, 23, with_root=True)
+    crowd.clip_id[:2] = abi.NO_CLIP
+    got = run_gpu(rig, multi, exact_arithmetic=exact, pose_path=pose_path)
+    ref = run_oracle(oracle32, rig, multi)
+    assert got["palette"].shape[1] == rig.palette_count
+    _check_all(got, ref, exact_pose=True, exact_skin=exact == 1, tag=f"multi[exact={exact}]:")
+    info = got["info"]
+    assert (info.skin_count, info.section_count, info.palette_count, info.joint_count) == (3, 4, rig.palette_count, rig.joint_count)
+    # the same vertices skinned through ONE skin (the rig this one was cut from): identical bits, no oracle involved
+    one = run_gpu(base, crowd, exact_arithmetic=exact, pose_path=pose_path, want=("position", "normal", "tangent", "world"))
+    ns = sum(s.vertex_count for s in rig.sections if s.skin >= 0)
+    for k in ("position", "normal", "tangent"):
+        assert_equal(got[k][:, :ns].view(np.uint32), one[k][:, :ns].view(np.uint32), f"{k}: several skins vs one skin")
+    assert_equal(got["world"], one["world"], "world")
+
+
+def test_unskinned_section_is_the_instance_uniform_applied_to_the_static_mesh(oracle32):
+    """shader.wgsl:143-152: instance.transform * vec4(position, 1), instance.normal * normal — with the InstanceUniform the
+    library exports for the section's node, applied on the host with the oracle's mat * vec."""
+    spec, base, rig, tmap = _avatar(seed=9)
+    crowd, multi = _multi_crowd(spec, base, tmap, 5)
+    prop = rig.sections[-1]
+    assert prop.skin == -1 and prop.vertex_count > 0
+    with api.Context(exact_arithmetic=1) as ctx:
+        r = api.Rig(ctx, rig)
+        c = api.Crowd(ctx, r, 5)
+        c.set_clocks(multi.tau, multi.clip_id)
+        c.set_morph_weights(multi.morph_weights)
+        c.evaluate(abi.STAGE_ALL, sync=True)
+        lay = r.section_layout(len(rig.sections) - 1)
+        assert (lay.node, lay.skin, lay.first_vertex, lay.vertex_count) == (prop.node, -1, prop.first_vertex, prop.vertex_count)
+        assert lay.first_palette_entry == rig.joint_count
+        ref = oracle32.evaluate(rig, multi.tau, multi.clip_id, multi.morph_weights)
+        pos, nrm, tan = c.positions(), c.normals(), c.tangents()
+        world = c.world()
+        for i in range(5):
+            iu = c.instance_uniform(i, prop.node)
+            want_iu = oracle32.instance_uniform(ref.world[i, prop.node])
+            assert_equal(iu, want_iu, f"InstanceUniform[{i}]")
+            assert iu[3] == 0 and iu[15] == 1 and not iu[28:].any() and not iu[[19, 23, 27]].any()
+            # transform = the node's world matrix, column-major
+            assert_equal(iu[:16].reshape(4, 4).T[:3].reshape(12), world[i, prop.node], "transform")
+            sl = slice(prop.first_vertex, prop.first_vertex + prop.vertex_count)
+            if prop.target_count == 0:  # static mesh: the reference's vertex shader on the rig's own arrays
+                for v in (0, prop.vertex_count // 2, prop.vertex_count - 1):
+                    gv = prop.first_vertex + v
+                    op, on, ot = oracle32.rigid_vertex(iu, rig.position[gv], rig.normal[gv], rig.tangent[gv, :3])
+                    assert_equal(pos[i, gv], op, "position"); assert_equal(nrm[i, gv], on, "normal"); assert_equal(tan[i, gv], ot, "tangent")
+            assert_equal(pos[i, sl], ref.position[i, sl], "prop positions")
+            assert_equal(nrm[i, sl], ref.normal[i, sl], "prop normals")
+        with pytest.raises(api.SkinrtError) as e:
+            c.instance_uniform(0, rig.node_count)
+        assert e.value.code == abi.E_RANGE
+        with pytest.raises(api.SkinrtError) as e:
+            c.interleaved_section(len(rig.sections) - 1, 0, abi.LAYOUT_COLOR_SKIN)
+        assert e.value.code == abi.E_INVALID
+        c.close(); r.close()
+
+
+def test_per_skin_and_per_section_exports(oracle32):
+    spec, base, rig, tmap = _avatar(seed=13)
+    n = 9
+    crowd, multi = _multi_crowd(spec, base, tmap, n)
+    dev = DeviceBuffers()
+    with api.Context() as ctx:
+        r = api.Rig(ctx, rig)
+        c = api.Crowd(ctx, r, n)
+        c.set_clocks(multi.tau, multi.clip_id)
+        c.set_morph_weights(multi.morph_weights)
+        c.evaluate(abi.STAGE_ALL, sync=True)
+        ref = oracle32.evaluate(rig, multi.tau, multi.clip_id, multi.morph_weights, want=("palette", "world"))
+        pos, nrm, tan = c.positions(), c.normals(), c.tangents()
+        for s, sk in enumerate(rig.skins):
+            lay = r.skin_layout(s)
+            assert (lay.first_palette_entry, lay.joint_count) == (rig.skin_first(s), sk.joint_node.shape[0])
+            J = lay.joint_count
+            for i in (0, n - 1):
+                u = c.skin_uniform_of(s, i)
+                assert_equal(u[:J], ref.palette[i, lay.first_palette_entry:lay.first_palette_entry + J], f"SkinMatrix skin {s}")
+                assert not u[J:].any()
+            out = dev.empty(n * 128 * 112)
+            c.skin_uniform_of_device(s, 0, n, out)
+            ctx.synchronize()
+            got = dev.download(out, (n, 128, 28), np.float32)
+            assert_equal(got[:, :J], ref.palette[:, lay.first_palette_entry:lay.first_palette_entry + J], f"device SkinMatrix skin {s}")
+            assert not got[:, J:].any()
+        assert_equal(c.skin_uniform(3), c.skin_uniform_of(0, 3), "skinrt_export_skin_uniform = skin 0")
+        rng = np.random.default_rng(4)
+        for si, sc in enumerate(rig.sections[:-1]):
+            for layout, na, stride in ((abi.LAYOUT_COLOR_SKIN, 4, 76), (abi.LAYOUT_TEXTURE_SKIN, 2, 68)):
+                attr = rng.random((sc.vertex_count, na), dtype=np.float32)
+                rec = c.interleaved_section(si, 2, layout, attr).reshape(sc.vertex_count, stride)
+                sl = slice(sc.first_vertex, sc.first_vertex + sc.vertex_count)
+                f = lambda a, b: rec[:, a:b].copy().view(np.float32)
+                assert_equal(f(0, 12), pos[2, sl], "position")
+                assert_equal(f(12, 12 + 4 * na), attr, "attr")
+                o = 12 + 4 * na
+                assert_equal(f(o, o + 12), nrm[2, sl], "normal")
+                assert_equal(f(o + 12, o + 24), tan[2, sl], "tangent")
+                assert_equal(rec[:, o + 24:o + 32].copy().view(np.uint16), rig.joints[0][sl], "joint_index: the section's own skin")
+                assert_equal(f(o + 32, o + 48), rig.weights[0][sl], "joint_weight")
+                dattr = dev.upload(attr)
+                out = dev.empty(n * sc.vertex_count * stride + 16)
+                c.interleaved_section_device(si, 0, n, layout, dattr, out)
+                ctx.synchronize()
+                got = dev.download(out, (n, sc.vertex_count * stride), np.uint8)
+                assert_equal(got[2], rec.reshape(-1), f"device records, section {si} layout {layout}")
+                for i in (0, n - 1):
+                    assert_equal(got[i], c.interleaved_section(si, i, layout, attr), "device = host records")
+        # InstanceUniform records for a node list, 256-byte stride (wgpu's dynamic offset alignment)
+        nodes = np.array([rig.sections[-1].node, 0, rig.node_count + 7, 3], np.uint32)
+        dn = dev.upload(nodes)
+        out = dev.empty(n * len(nodes) * 256, fill=0xCD)
+        c.instance_uniform_device(0, n, dn, len(nodes), 256, out)
+        ctx.synchronize()
+        got = dev.download(out, (n, len(nodes), 64), np.float32)
+        for i in range(n):
+            for q, node in enumerate(nodes):
+                if node >= rig.node_count:
+                    assert not got[i, q, :31].any(), "a node index out of range writes a zero record"
+                else:
+                    assert_equal(got[i, q, :31], oracle32.instance_uniform(ref.world[i, node]), f"record ({i},{q})")
+        assert (got[..., 31:].view(np.uint32) == 0xCDCDCDCD).all(), "bytes past 124 of a record are not written"
+        c.close(); r.close()
+    dev.close()
+
+
+def test_one_pose_stage_feeds_every_skin():
+    """Three skins on one node tree cost ONE pose stage (nodes sampled and propagated once, a palette of all skins'
+    joints), not three: its time stays near the one-skin rig's, far from 3x."""
+    spec = synth.scaled(synth.CONFIGS["c3"], verts=6000, targets=4, instances=4000)
+    base = synth.make_rig(spec)
+    rig, tmap = synth.make_multi_rig(base, seed=3)
+    crowd, multi = _multi_crowd(spec, base, tmap, spec.instances)
+    ms = {}
+    for name, rg, cr in (("one", base, crowd), ("multi", rig, multi)):
+        with api.Context() as ctx:
+            r = api.Rig(ctx, rg)
+            c = api.Crowd(ctx, r, spec.instances)
+            c.set_clocks(cr.tau, cr.clip_id)
+            c.set_morph_weights(cr.morph_weights)
+            best = 1e9
+            for _ in range(6):
+                c.evaluate(abi.STAGE_ALL, sync=True)
+                best = min(best, c.stage_ms()[0])
+            ms[name] = best
+            c.close(); r.close()
+    print(f"pose stage: one skin {ms['one']:.3f} ms, three skins + prop {ms['multi']:.3f} ms "
+          f"(palette {base.palette_count} -> {rig.palette_count} entries)")
+    assert ms["multi"] < 1.6 * ms["one"] + 0.02
+
+
+def test_weights_channels_drive_their_own_section(oracle32):
+    """A `weights` channel belongs to the mesh on its node (its width = that mesh's target count); an instance whose clip
+    carries channels for some sections keeps the host's weights for the others."""
+    spec, base, rig, tmap = _avatar(seed=21)
+    # clip 1: drop the face's channel, so only the other sections are channel-driven there
+    face = rig.sections[1]
+    assert face.target_count > 0
+    before = len(rig.clips[1])
+    rig.clips[1] = [ch for ch in rig.clips[1] if not (ch.path == abi.PATH_WEIGHTS and ch.target_node == face.node)]
+    assert len(rig.clips[1]) == before - 1
+    crowd, multi = _multi_crowd(spec, base, tmap, 31)
+    got = run_gpu(rig, multi, exact_arithmetic=1)
+    ref = run_oracle(oracle32, rig, multi)
+    _check_all(got, ref, exact_skin=True, tag="weights channels per section:")
+    assert (multi.clip_id == 1).any() and (multi.clip_id == 2).any()

@@ -373,3 +373,83 @@ def test_tangent_modes(oracle32):
     # trailing vertices that do not fill a triangle are ignored (positions.len() / 3, tangent.rs:41)
     t = oracle32.calculate_tangent(4, np.concatenate([pos, pos[:2]]))
     assert np.isfinite(t[:3]).all() and np.isnan(t[3:]).all()
+
+
+# ---- un-skinned meshes and several skins (skinrt.h ABI 6) ------------------------------------------------------------
+
+def test_instance_uniform_layout_and_normal_matrix(oracle32):
+    """InstanceUniform{transform, normal, padding} — renderer/src/renderer/uniform/transform.rs:8-14, :27-42: the matrix
+    column-major, then Mat3(inverse(m)^T) as three vec4 columns with w = 0, then 12 bytes of padding: 124 bytes."""
+    m = mat([[2, 0, 0, 0], [0, 4, 0, 0], [0, 0, 8, 0], [5, 6, 7, 1]])
+    iu = oracle32.instance_uniform(m)
+    assert iu.nbytes == 124
+    assert iu[:16].tolist() == m.tolist()
+    assert iu[16:28].tolist() == [0.5, 0, 0, 0, 0, 0.25, 0, 0, 0, 0, 0.125, 0]
+    assert iu[28:].tolist() == [0, 0, 0]
+
+
+def test_unskinned_vertex_is_instance_transform_times_position(oracle32):
+    """color_vs_main / texture_vs_main — shader.wgsl:143-152, :167-176: instance.transform * vec4(position, 1),
+    instance.normal * normal, instance.normal * tangent (not normalised; the outline variants normalise, :198-199)."""
+    m = mat([[0, 2, 0, 0], [-2, 0, 0, 0], [0, 0, 2, 0], [1, 2, 3, 1]])  # quarter turn about z, scale 2, translation
+    iu = oracle32.instance_uniform(m)
+    p, n, t = oracle32.rigid_vertex(iu, [1, 0, 0], [1, 0, 0], [0, 1, 0])
+    assert p.tolist() == [1, 4, 3] and n.tolist() == [0, 0.5, 0] and t.tolist() == [-0.5, 0, 0]
+    p, n, t = oracle32.rigid_vertex(iu, [1, 0, 0], [1, 0, 0], [0, 1, 0], normalize=1)
+    assert n.tolist() == [0, 1, 0] and t.tolist() == [-1, 0, 0]
+
+
+def test_sections_use_their_own_skin_and_props_their_node(oracle32):
+    """Two skins over one tree naming the same nodes in different orders, and a prop on a node without a skin: a vertex's
+    joint index counts inside ITS section's skin (node.rs:95, loader/gltf/mod.rs:1124-1166)."""
+    from renderer_amd.abi import Section, Skin
+    rig = rig_of(parent=[-1, 0, 0], t=[[0, 0, 0], [10, 0, 0], [0, 20, 0]],
+                 pos=[(1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1)],
+                 joints=[np.array([[0, 0, 0, 0], [1, 0, 0, 0], [0, 0, 0, 0], [9, 9, 9, 9]], np.uint16)],
+                 weights=[np.array([[1, 0, 0, 0], [1, 0, 0, 0], [1, 0, 0, 0], [np.nan] * 4], np.float32)])
+    rig.skins = [Skin(np.array([1, 2], np.uint32)), Skin(np.array([2, 1], np.uint32))]
+    rig.sections = [Section(0, 0, 0, 2), Section(0, 1, 2, 1), Section(2, -1, 3, 1)]
+    assert rig.palette_count == 5
+    r = oracle32.evaluate(rig, tau=[0.0], want=("position", "palette"))
+    # vertex 0: skin 0 joint 0 = node 1; vertex 1: skin 0 joint 1 = node 2; vertex 2: skin 1 joint 0 = node 2; vertex 3: node 2's world
+    assert r.position[0].tolist() == [[11, 1, 1], [1, 21, 1], [1, 21, 1], [1, 21, 1]]
+    assert [r.palette[0, k, 12:15].tolist() for k in range(5)] == [[10, 0, 0], [0, 20, 0], [0, 20, 0], [10, 0, 0], [0, 20, 0]]
+
+
+def test_section_targets_count_rows_from_the_sections_first_vertex(oracle32):
+    from renderer_amd.abi import Section
+    rig = rig_of(parent=[-1, 0], pos=[(0, 0, 0)] * 5, joint_node=(0,),
+                 targets=[MorphTarget(position=np.array([[1, 0, 0], [2, 0, 0]], np.float32)),                       # dense over section 0
+                          MorphTarget(position=np.array([[0, 4, 0]], np.float32), indices=np.array([2], np.uint32))])  # row 2 of section 1
+    rig.sections = [Section(0, 0, 0, 2, 0, 1), Section(1, 0, 2, 3, 1, 1)]
+    r = oracle32.evaluate(rig, tau=[0.0], morph_weights=[[0.5, 0.25]], want=("position",))
+    assert r.position[0].tolist() == [[0.5, 0, 0], [1, 0, 0], [0, 0, 0], [0, 0, 0], [0, 1, 0]]
+
+
+def test_weights_channels_are_matched_to_sections_by_node(oracle32):
+    from renderer_amd.abi import Section
+    ch = Channel(1, abi.PATH_WEIGHTS, abi.INTERP_LINEAR, np.array([0, 2], np.float32), np.array([[0.0], [1.0]], np.float32))
+    rig = rig_of(parent=[-1, 0], pos=[(0, 0, 0)] * 2, joint_node=(0,), clips=[[ch]],
+                 targets=[MorphTarget(position=np.array([[8, 0, 0]], np.float32)), MorphTarget(position=np.array([[0, 8, 0]], np.float32))])
+    rig.sections = [Section(0, 0, 0, 1, 0, 1), Section(1, 0, 1, 1, 1, 1)]
+    r = oracle32.evaluate(rig, tau=[0.5], morph_weights=[[0.5, 0.5]], want=("position", "key_index"))
+    # section 0 keeps the host's weight (0.5), section 1 (node 1) takes the channel's sample at tau = 0.5: 0.25
+    assert r.position[0].tolist() == [[4, 0, 0], [0, 2, 0]] and r.key_index[0].tolist() == [0]
+
+
+def test_sampled_evaluation_is_a_subset_of_the_full_one(oracle32):
+    """orc_evaluate_sampled (the full-size parity tests' oracle leg): vertex v of instance i is computed when
+    v % step == (phase + i) % step and lands in row v // step — same arithmetic, same bits."""
+    from renderer_amd import synth
+    spec = synth.tiny_spec(seed=3, verts=333, targets=5, target_mode="sparse", target_frac=0.2)
+    rig = synth.make_rig(spec)
+    cr = synth.make_crowd(spec, rig, instances=9)
+    full = oracle32.evaluate(rig, cr.tau, cr.clip_id, cr.morph_weights, want=("position", "normal", "tangent"))
+    step, phase = 7, 3
+    part = oracle32.evaluate_mt(rig, cr.tau, cr.clip_id, cr.morph_weights, want=("position", "normal", "tangent"), vertex_step=step,
+                                vertex_phase=phase, threads=3)
+    for i in range(9):
+        ph = (phase + i) % step
+        n = len(range(ph, 333, step))
+        for k in ("position", "normal", "tangent"):
+            assert np.array_equal(getattr(part, k)[i, :n].view(np.uint32), getattr(full, k)[i, ph::step].view(np.uint32)), (i, k)

@@ -93,7 +93,8 @@ def rust_layout(fields):
 def test_every_header_struct_is_bound_field_for_field(tmp_path):
     hs = header_structs()
     assert set(hs) == {"skinrt_config", "skinrt_channel_desc", "skinrt_clip_desc", "skinrt_morph_target_desc", "skinrt_rig_desc",
-                       "skinrt_rig_info", "skinrt_placement_info"}
+                       "skinrt_rig_info", "skinrt_placement_info", "skinrt_skin_desc", "skinrt_section_desc", "skinrt_skin_layout",
+                       "skinrt_section_layout"}
     want = c_layout(hs, tmp_path)
     rs = rust_structs()
     for s, fields in hs.items():
@@ -113,7 +114,8 @@ def test_ctypes_mirror_matches_every_field_too(tmp_path):
     want = c_layout(hs, tmp_path)
     mirror = {"skinrt_config": abi.Config, "skinrt_channel_desc": abi.ChannelDesc, "skinrt_clip_desc": abi.ClipDesc,
               "skinrt_morph_target_desc": abi.MorphTargetDesc, "skinrt_rig_desc": abi.RigDesc, "skinrt_rig_info": abi.RigInfo,
-              "skinrt_placement_info": abi.PlacementInfo}
+              "skinrt_placement_info": abi.PlacementInfo, "skinrt_skin_desc": abi.SkinDesc, "skinrt_section_desc": abi.SectionDesc,
+              "skinrt_skin_layout": abi.SkinLayout, "skinrt_section_layout": abi.SectionLayout}
     for s, fields in hs.items():
         t = mirror[s]
         assert [n for n, _ in t._fields_] == fields, s
