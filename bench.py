@@ -49,7 +49,8 @@ def algorithmic_bytes(rig, instances):
 def cpu_baseline(rig, spec, budget_s=15.0):
     """Oracle (fp32 C restatement, reference op order, -O2 -ffp-contract=off) timed on this
     box's host cores on a bounded sample of the same workload: single thread (the reference has
-    one render thread, renderer/src/state.rs:236), then instance-parallel over 16 threads."""
+    one render thread, renderer/src/state.rs:236), then instance-parallel over this box's share of the host's cores
+    (a GPU box shows the whole machine's CPUs in os.cpu_count(); its share is what OMP_NUM_THREADS says)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle.oracle import Oracle, OracleResult
 
@@ -67,7 +68,7 @@ def cpu_baseline(rig, spec, budget_s=15.0):
     t0 = time.perf_counter()
     orc.evaluate(rig, crowd.tau, crowd.clip_id, crowd.morph_weights, want=want, desc=desc, into=res)
     dt1 = time.perf_counter() - t0
-    threads = 16
+    threads = host_threads()
     chunks = [(k * n // threads, (k + 1) * n // threads) for k in range(threads)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:
@@ -80,6 +81,101 @@ def cpu_baseline(rig, spec, budget_s=15.0):
     many = {"value": n * V / dtm, "unit": "skinned vertices/s", "cores": threads, "kind": "port", "sample": sample,
             "seconds": round(dtm, 3), "host_cpus": os.cpu_count()}
     return one, many
+
+
+def host_threads() -> int:
+    """Worker threads for the CPU baseline: the box's CPU share (OMP_NUM_THREADS where the harness sets it), never more
+    than the machine has."""
+    have = os.cpu_count() or 1
+    try:
+        share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        share = 0
+    return max(1, min(have, share) if share > 0 else have)
+
+
+def visible_gpus() -> int:
+    """GPUs this process would see, WITHOUT opening one (the parent of the ranks must not initialise the GPU before it
+    starts them): KFD topology nodes with SIMDs, cut down by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES lists when they are set."""
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split(None, 1) for line in open(path).read().splitlines() if " " in line)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+class FrameLoop:
+    """The bench's frame loop, separate from what it drives so that the CPU tests can run the SAME step / fence /
+    exchange / timing code with two gloo ranks and the oracle standing in for the crowd (tests/test_bench_loop.py):
+    `crowd` needs evaluate(stages) (and advance_clocks(dt) when clocks advance), `ctx` synchronize() and `stream`;
+    `aabb_rows` is a torch tensor [mine, 6] (device memory of the crowd's bounds on a GPU) or None without a launcher."""
+
+    def __init__(self, crowd, ctx, aabb_rows, total: int, world: int, launched: bool, advance_dt=None):
+        self.crowd, self.ctx, self.total, self.world, self.launched = crowd, ctx, total, world, launched
+        self.advance_dt = advance_dt
+        self.torch = self.dist = None
+        self.on_gpu = False
+        self.exchange = None
+        if launched:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            self.on_gpu = bool(aabb_rows.is_cuda)
+            # The exchange overlaps the next frame (shard.OverlappedRowGather: RCCL on a side stream behind an event of the
+            # library's stream; the next frame waits for a 24-byte-per-instance copy, never for the collective or the
+            # host).  Rehearsed with one rank: a host synchronize plus the collective in line cost 0.19 ms of a 4.5 ms
+            # frame, the collective in line on the library's stream 0.16 ms, this form 0.01 ms.
+            self.exchange = shard.OverlappedRowGather(aabb_rows, total, world, ctx.stream if self.on_gpu else 0)
+
+    def step(self, gather=True, advance=None):
+        gather = gather and self.launched
+        if gather:
+            self.exchange.before_frame()
+        if (self.advance_dt is not None) if advance is None else advance:
+            self.crowd.advance_clocks(self.advance_dt if self.advance_dt is not None else 1.0 / 60.0)  # device-side, stream-ordered
+        self.crowd.evaluate(abi.STAGE_ALL)
+        if gather:
+            self.exchange.after_frame()
+
+    def fence(self):
+        self.ctx.synchronize()
+        if self.launched:
+            if self.on_gpu:
+                self.torch.cuda.synchronize()
+            self.dist.barrier()
+            if self.on_gpu:
+                self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x: float) -> float:
+        if not self.launched:
+            return x
+        tt = self.torch.tensor([x], dtype=self.torch.float64, device=self.exchange.local.device)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def timed(self, steps: int, gather=True, advance=None, per_step=None) -> float:
+        """EXACTLY `steps` frames between two fences; the slowest rank's wall time."""
+        self.fence()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.step(gather, advance)
+            if per_step is not None:
+                per_step(k)
+        self.fence()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def gathered_bounds(self):
+        return self.exchange.result() if self.exchange is not None else None
 
 
 def measured_bandwidth(device: int):
@@ -128,8 +224,7 @@ def spawn_ranks(n: int, argv):
     and exit with their status.  Refuses (exit 2, no JSON line) when the node has fewer GPUs."""
     import socket
     import subprocess
-    import torch  # device_count() does not initialise the GPU
-    have = torch.cuda.device_count()
+    have = visible_gpus()  # sysfs: this process never opens a GPU
     if have < n:
         sys.stderr.write(f"bench.py: --gpus {n} asked for, {have} visible: refusing to print a line for ranks that do not exist\n")
         sys.exit(2)
@@ -150,6 +245,9 @@ def main():
     ap.add_argument("--instances", type=int, default=None, help="override the TOTAL instance count")
     ap.add_argument("--no-vertex-gather", action="store_true", help="N>1: skip the extra vertex all-gather measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--advance-clocks", action="store_true",
+                    help="every timed frame also advances the instances' clocks on the device (skinrt_advance_clocks, 1/60 s): the frame "
+                         "a renderer's loop runs; without it the loop is timed after the main region and reported as frame_loop")
     ap.add_argument("--exact", type=int, default=0, choices=[0, 1, 2],
                     help="skinrt_config.exact_arithmetic: 0 chosen per rig, 1 contraction-free kernels (bit-equal to the oracle), 2 FMA kernels")
     args = ap.parse_args()
@@ -218,54 +316,23 @@ def main():
             pptr, _ = crowd.device_pointer(what)
             vert_t.append(torch.as_tensor(shard.DeviceArray(pptr, (mine, V * 3)), device=dev))
 
-    # The exchange step overlaps the next frame (shard.OverlappedRowGather: RCCL on a side stream behind an event of the
-    # library's stream; the next frame waits for a 24-byte-per-instance copy, never for the collective or the host).
-    # Rehearsed with one rank: a host synchronize plus the collective in line cost 0.19 ms of a 4.5 ms frame, the
-    # collective in line on the library's stream 0.16 ms, this form 0.01 ms.
-    exchange_step = shard.OverlappedRowGather(aabb_t, total, world, ctx.stream) if launched else None
-
-    def step(gather=True):
-        if launched and gather:
-            exchange_step.before_frame()
-        crowd.evaluate(abi.STAGE_ALL)
-        if launched and gather:
-            exchange_step.after_frame()
-
-    def fence():
-        ctx.synchronize()
-        if launched:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def max_over_ranks(x):
-        if not launched:
-            return x
-        tt = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
+    loop = FrameLoop(crowd, ctx, aabb_t, total, world, launched, advance_dt=(1.0 / 60.0) if args.advance_clocks else None)
+    step, fence, max_over_ranks = loop.step, loop.fence, loop.max_over_ranks
 
     for _ in range(args.warmup):
         step()
-    fence()
     stage = np.zeros((args.steps, 4))
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step()
+
+    def stamp(k):
         stage[k] = crowd.stage_ms()  # HIP events on the library's stream, around each kernel
-    fence()
-    dt = max_over_ranks(time.perf_counter() - t0)
+
+    dt = loop.timed(args.steps, per_step=stamp)
 
     # next to the frame (kernels + bounds all-gather = `value`), the kernels alone and the
     # frame with the skinned vertex buffers gathered as well (xGMI-bound by construction)
     exchange = None
     if launched:
-        fence()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            step(gather=False)
-        fence()
-        dt_k = max_over_ranks(time.perf_counter() - t0)
+        dt_k = loop.timed(args.steps, gather=False)
         exchange = {"kernels_only_ms": dt_k / args.steps * 1e3, "with_aabb_allgather_ms": dt / args.steps * 1e3,
                     "with_vertex_allgather_ms": None}
         if not args.no_vertex_gather:
@@ -280,17 +347,56 @@ def main():
             exchange["vertex_allgather"] = {"bytes_received_per_rank": moved, "steps": 1,
                                             "how": "position, normal, tangent one after the other, row chunks through one 8 GiB buffer"}
 
+    # What a renderer's loop does per frame: new inputs, then the frame.  The clocks advance ON THE DEVICE, stream-ordered
+    # (skinrt_advance_clocks): nothing drains the GPU between frames.  Measured next to the plain frame.
+    frame_loop = None
+    if not args.advance_clocks:
+        n_loop = min(args.steps, 30)
+        dt_adv = loop.timed(n_loop, advance=True)
+        dt_same = loop.timed(n_loop, advance=False)
+        frame_loop = {"ms_per_step_advancing_clocks": dt_adv / n_loop * 1e3, "ms_per_step_evaluate_only": dt_same / n_loop * 1e3,
+                      "steps": n_loop, "how": "skinrt_advance_clocks(1/60 s) + skinrt_evaluate per frame, no host wait inside the loop"}
+        crowd.set_clocks(crowd_in.tau, crowd_in.clip_id)
+
+    # The same frames with the three output arrays where three plain hipMalloc calls put them (no steering over the HBM's
+    # thirds): what the kernels do without placement.hip.  A second context + crowd, N = 1 only.
+    plain_ms = None
+    if n_gpus == 1 and crowd.placement["strategy"] != "plain":
+        try:
+            ctx2 = api.Context(device=local_rank, exact_arithmetic=args.exact, output_placement=1)
+            rig2 = api.Rig(ctx2, rig_data)
+            crowd2 = api.Crowd(ctx2, rig2, mine)
+            crowd2.set_clocks(crowd_in.tau, crowd_in.clip_id)
+            if crowd_in.morph_weights is not None:
+                crowd2.set_morph_weights(crowd_in.morph_weights)
+            acc = []
+            for k in range(20):
+                crowd2.evaluate(abi.STAGE_ALL, sync=True)
+                if k >= 10:
+                    acc.append(crowd2.stage_ms()[1])
+            plain_ms = float(np.mean(acc))
+            crowd2.close(); rig2.close(); ctx2.close()
+        except api.SkinrtError as e:  # no room for a second crowd: a reported extra, never a reason to lose the line
+            plain_ms = None
+            sys.stderr.write(f"bench.py: plain-placement crowd skipped: {e}\n")
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = total * V * args.steps / dt
         skin_ms = float(stage[:, 1].mean())
         bytes_launch = algorithmic_bytes(rig_data, mine)
         achieved = bytes_launch / (skin_ms * 1e-3)
+        # HBM bytes per launch from rocprofv3 PMC passes of THIS command (separate --pmc runs, corrected as
+        # /opt/skills/guides/MI355X_MICROARCH.md prescribes) on another box of the pool, committed under profiles/; a plain
+        # `python bench.py` cannot read counters of its own run, so the source is named beside the number
         traffic = None
+        traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{name}:{mine}")
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"{name}:{mine}")
+                traffic_source = tj.get("source")
             except Exception:
                 traffic = None
         info = rig.info
@@ -307,16 +413,22 @@ def main():
                        "stages": "pose+morph+skin+aabb" + ("+allgather(aabb)" if launched else ""),
                        "exact_arithmetic": int(info.exact_arithmetic), "exact_arithmetic_config": args.exact, "parallelism": f"instances sharded x{n_gpus}"},
             "stage_ms": {"pose": float(stage[:, 0].mean()), "skin_morph": skin_ms,
-                         "aabb_reduce": float(stage[:, 2].mean()), "device_span": float(stage[:, 3].mean())},
+                         "aabb_reduce": float(stage[:, 2].mean()), "device_span": float(stage[:, 3].mean()),
+                         "skin_morph_plain_placement": plain_ms},
             "roofline": {"bound": "hbm", "kernel": "skin stage = k_classify + k_skin2 (morph + linear-blend skinning + per-tile bounds)", "achieved": achieved / 1e9,
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": skin_ms, "traffic": traffic},
+                         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": skin_ms, "traffic": traffic,
+                         "traffic_source": traffic_source},
             "output_placement": crowd.placement,
             "rig_compile": {"tiles": info.tile_count, "max_tile_joints": info.max_tile_joints,
                             "lds_tiles": info.lds_tiles, "morph_entries": int(info.morph_entries)},
         }
         if exchange is not None:
             out["exchange"] = exchange
+        if frame_loop is not None:
+            out["frame_loop"] = frame_loop
+        if args.advance_clocks:
+            out["config"]["stages"] = "advance_clocks+" + out["config"]["stages"]
         try:
             if n_gpus != 1:
                 raise RuntimeError("measured at N=1 only")

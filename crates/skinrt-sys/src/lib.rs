@@ -81,6 +81,7 @@ pub struct skinrt_config {
     pub skin_path: u32,
     pub output_placement: u32,
     pub allow_experimental_build: u32,
+    pub placement_max_filler_gib: u32,
 }
 
 #[repr(C)]

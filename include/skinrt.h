@@ -119,10 +119,18 @@ typedef struct skinrt_config {
      * the thirds at ~7 TB/s; the arrays are steered there with transient filler allocations that are
      * freed before the call returns (up to two thirds of the device's free memory is reserved for
      * the duration of skinrt_create_crowd), and the result is measured (skinrt_get_output_placement).
-     * 1: three plain hipMalloc calls, no filler, no measurement. */
+     * 1: three plain hipMalloc calls, no filler, no measurement.
+     * The steering assumes what was measured on MI355X / ROCm 7.2: the VRAM manager hands memory out lowest-first and
+     * the bytes in use (hipMemGetInfo) are the allocation frontier.  Other allocations of the process, other crowds,
+     * memory freed earlier or another process on the GPU can break that; the arrays are then used where they landed,
+     * results never depend on it, and skinrt_placement_info.strategy says what happened.  While skinrt_create_crowd
+     * runs, the filler is real allocated memory: a concurrent allocation of another thread or process may fail. */
     uint32_t output_placement;
     /* 1: skinrt_init accepts a library whose skinrt_build_flags() is not 0 (measurement builds). */
     uint32_t allow_experimental_build;
+    /* output_placement = 0: the most the transient filler may reserve, in GiB (0: no limit but the free memory).
+     * When the detour to the next third needs more, the arrays are allocated plainly (strategy 3). */
+    uint32_t placement_max_filler_gib;
 } skinrt_config;
 
 /* ---- flat rig ("loader output", SURVEY.md §8a rows a1,a5-a8,a11,a13) ---------------- */
@@ -277,7 +285,12 @@ typedef struct skinrt_section_layout {
 /* What skinrt_create_crowd did with the output arrays and what it measured (all zero for small crowds
  * and for output_placement=1). */
 typedef struct skinrt_placement_info {
-    uint32_t strategy;          /* 0: plain allocations, 1: steered with filler allocations */
+    /* 0: plain allocations (small crowd, output_placement = 1, not an MI355X);
+     * 1: steered with filler allocations and the measurement confirms it (spread_gain >= 1.15);
+     * 2: steered, but the arrays did NOT end up spread (spread_gain < 1.15: the allocator did not behave as assumed —
+     *    fragmented or shared memory); they are used as they are, the stage then writes at the one-region rate;
+     * 3: not steered: the detour did not fit the free memory or placement_max_filler_gib; plain allocations, measured. */
+    uint32_t strategy;
     uint32_t reserved;
     uint64_t filler_bytes;      /* transient reservation during skinrt_create_crowd */
     float probe_together_ms;    /* the skin stage's store pattern, no arithmetic, on all three arrays */

@@ -39,6 +39,7 @@ class Config(C.Structure):
         ("skin_path", C.c_uint32),
         ("output_placement", C.c_uint32),
         ("allow_experimental_build", C.c_uint32),
+        ("placement_max_filler_gib", C.c_uint32),
     ]
 
 

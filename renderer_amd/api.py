@@ -131,7 +131,7 @@ def _check(rc: int):
 
 def make_config(device: int = 0, cubic_quirk: int = 1, normalize_outputs: int = 0, reference_limits: int = 0,
                 exact_arithmetic: int = 0, pose_path: int = 0, skin_path: int = 0, output_placement: int = 0,
-                allow_experimental_build: Optional[int] = None) -> Config:
+                allow_experimental_build: Optional[int] = None, placement_max_filler_gib: int = 0) -> Config:
     cfg = Config()
     cfg.struct_size = C.sizeof(Config)
     cfg.device = device
@@ -146,6 +146,7 @@ def make_config(device: int = 0, cubic_quirk: int = 1, normalize_outputs: int = 
     if allow_experimental_build is None:
         allow_experimental_build = 1 if os.environ.get("SKINRT_ALLOW_EXPERIMENTAL") == "1" else 0
     cfg.allow_experimental_build = allow_experimental_build
+    cfg.placement_max_filler_gib = placement_max_filler_gib
     return cfg
 
 
@@ -268,7 +269,8 @@ class Crowd:
         """What skinrt_create_crowd did with the output arrays and what it measured."""
         info = PlacementInfo()
         _check(self.ctx.lib.skinrt_get_output_placement(self.handle, C.byref(info)))
-        return {"strategy": "steered" if info.strategy else "plain", "filler_GiB": info.filler_bytes / 2 ** 30,
+        names = {0: "plain", 1: "steered", 2: "steered-without-effect", 3: "not-steered-no-room"}
+        return {"strategy": names.get(info.strategy, str(info.strategy)), "filler_GiB": info.filler_bytes / 2 ** 30,
                 "probe_together_ms": info.probe_together_ms, "probe_alone_ms": info.probe_alone_ms,
                 "spread_gain": info.spread_gain, "probe_GBps": info.probe_GBps}
 

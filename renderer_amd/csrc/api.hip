@@ -432,7 +432,8 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
     {   // the three output arrays: placed over the HBM's regions and measured (placement.hip)
         const size_t out_bytes = I * h.V * 12;
         void *p = nullptr, *n = nullptr, *t = nullptr;
-        hipError_t e = allocate_outputs(ctx->cfg.device, out_bytes, h.V, instances, ctx->cfg.output_placement, ctx->stream, &p, &n, &t, &c->place);
+        hipError_t e = allocate_outputs(ctx->cfg.device, out_bytes, h.V, instances, ctx->cfg.output_placement, ctx->cfg.placement_max_filler_gib, ctx->stream, &p, &n, &t,
+                                        &c->place);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             skinrt_destroy_crowd(c);

@@ -136,7 +136,7 @@ hipError_t tangent_static_area(int device, void** ptr, size_t* bytes);   // the 
 hipError_t launch_tangents(const float* pos, const uint32_t* indices, uint32_t vertices, uint32_t corners, void* work, size_t work_bytes,
                            float* out, hipStream_t s);
 // placement.hip: the three output arrays, steered over the HBM's regions and measured
-hipError_t allocate_outputs(int device, size_t bytes_each, uint32_t V, uint32_t I, uint32_t mode, hipStream_t s,
+hipError_t allocate_outputs(int device, size_t bytes_each, uint32_t V, uint32_t I, uint32_t mode, uint32_t max_filler_gib, hipStream_t s,
                             void** pos, void** nrm, void** tan, skinrt_placement_info* info);
 hipError_t launch_fill_morph_weights(float* mw, const float* defaults, uint32_t I, uint32_t M, hipStream_t s);
 

@@ -184,3 +184,89 @@ def test_c3_schedule_independence_under_instance_permutation():
             assert_equal(c.normals(j, 1).view(np.uint32), nr.view(np.uint32), f"normal, shuffled instance {j}")
             assert_equal(c.tangents(j, 1).view(np.uint32), tg.view(np.uint32), f"tangent, shuffled instance {j}")
         c.close(); r.close()
+
+
+# ---- the WHOLE crowd against the oracle (VERDICT r2 "weak 2") ---------------------------------------------------------
+# Every instance's bounds (min / max over ALL its vertices: every (tile, instance block, work list) combination takes
+# part) and every 257th vertex of every instance (the phase walks with the instance: a block of 80 instances meets
+# every 256-vertex tile about 80 times) are computed by the fp32 oracle on the host's cores and compared with the
+# GPU's: bit for bit with exact_arithmetic = 1, at 1e-5 rel / 1e-6 abs in the default arithmetic.
+import functools
+import time
+
+VERTEX_STEP = 257
+
+
+@functools.lru_cache(maxsize=2)
+def _whole_crowd_reference(name, first, count):
+    from oracle.oracle import Oracle
+    o = Oracle("f32")
+    spec = synth.CONFIGS[name]
+    rig = synth.make_rig(spec)
+    n = spec.instances if count is None else count
+    crowd = synth.make_crowd(spec, rig, instances=n, first=first)
+    t0 = time.perf_counter()
+    bounds = o.evaluate_mt(rig, crowd.tau, crowd.clip_id, crowd.morph_weights, want=("aabb",)).aabb
+    t1 = time.perf_counter()
+    part = o.evaluate_mt(rig, crowd.tau, crowd.clip_id, crowd.morph_weights, want=("position", "normal", "tangent"),
+                         vertex_step=VERTEX_STEP, vertex_phase=0)
+    print(f"[oracle] {name}: bounds of {n} instances x {rig.vertex_count} vertices in {t1 - t0:.1f} s, "
+          f"every {VERTEX_STEP}th vertex in {time.perf_counter() - t1:.1f} s")
+    return rig, crowd, bounds, part
+
+
+def whole_crowd(name, exact, first=0, count=None):
+    rig, crowd, ref_bounds, part = _whole_crowd_reference(name, first, count)
+    n, V = crowd.tau.shape[0], rig.vertex_count
+    with api.Context(exact_arithmetic=1 if exact else 0) as ctx:
+        r = api.Rig(ctx, rig)
+        c = api.Crowd(ctx, r, n)
+        c.set_clocks(crowd.tau, crowd.clip_id)
+        if crowd.morph_weights is not None:
+            c.set_morph_weights(crowd.morph_weights)
+        c.evaluate(abi.STAGE_ALL, sync=True)
+        mode = r.info.exact_arithmetic   # 1: all outputs carry the oracle's bits, 2: positions do, 0: fused
+        bounds = c.aabbs()
+        if mode:
+            assert_equal(bounds, ref_bounds, f"{name}: bounds of all {n} instances")
+        else:
+            assert_close(bounds, ref_bounds, f"{name}: bounds of all {n} instances")
+        rows = part.position.shape[1]
+        chunk = max(1, (256 << 20) // (V * 12))
+        q = np.arange(rows, dtype=np.int64)[None, :] * VERTEX_STEP
+        t0 = time.perf_counter()
+        for a in range(0, n, chunk):
+            b = min(n, a + chunk)
+            idx = (np.arange(a, b, dtype=np.int64) % VERTEX_STEP)[:, None] + q
+            valid = idx < V
+            idx = np.minimum(idx, V - 1)[:, :, None]
+            for k, fetch in (("position", c.positions), ("normal", c.normals), ("tangent", c.tangents)):
+                got = np.take_along_axis(fetch(a, b - a), idx, axis=1)[valid]
+                want = getattr(part, k)[a:b][valid]
+                if mode == 1 or (mode == 2 and k == "position"):
+                    assert_equal(got, want, f"{name}: {k}, instances {a}..{b}")
+                else:
+                    assert_close(got, want, f"{name}: {k}, instances {a}..{b}")
+        print(f"[gpu] {name}: compared {n} x {rows} sampled vertices x 3 attributes in {time.perf_counter() - t0:.1f} s (arithmetic mode {mode})")
+        c.close(); r.close()
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_c2_whole_crowd_against_the_oracle(exact):
+    whole_crowd("c2", exact)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_c3_whole_crowd_against_the_oracle(exact):
+    whole_crowd("c3", exact)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_c5_whole_crowd_against_the_oracle(exact):
+    whole_crowd("c5", exact)
+
+
+def test_c4_shard_of_8_whole_crowd_against_the_oracle():
+    from renderer_amd import shard
+    lo, hi = shard.shard_range(synth.CONFIGS["c4"].instances, 3, 8)
+    whole_crowd("c4", True, first=lo, count=hi - lo)
