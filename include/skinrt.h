@@ -115,21 +115,21 @@ typedef struct skinrt_config {
     uint32_t skin_path;
     /* Where skinrt_create_crowd puts the position / normal / tangent arrays of a large crowd
      * (3 arrays >= 1 GiB together).  0: one array per third of the device's physical HBM address
-     * space — on MI355X a write stream confined to one third runs at ~5.4 TB/s, streams spread over
-     * the thirds at ~7 TB/s; the arrays are steered there with transient filler allocations that are
-     * freed before the call returns (up to two thirds of the device's free memory is reserved for
-     * the duration of skinrt_create_crowd), and the result is measured (skinrt_get_output_placement).
-     * 1: three plain hipMalloc calls, no filler, no measurement.
-     * The steering assumes what was measured on MI355X / ROCm 7.2: the VRAM manager hands memory out lowest-first and
-     * the bytes in use (hipMemGetInfo) are the allocation frontier.  Other allocations of the process, other crowds,
-     * memory freed earlier or another process on the GPU can break that; the arrays are then used where they landed,
-     * results never depend on it, and skinrt_placement_info.strategy says what happened.  While skinrt_create_crowd
-     * runs, the filler is real allocated memory: a concurrent allocation of another thread or process may fail. */
+     * space where that can be had — on MI355X a write stream confined to one third runs at ~5.4 TB/s, streams
+     * spread over the thirds at ~7 TB/s.  hipMalloc gives no say over physical placement and the VRAM manager's
+     * habits differ between boxes, so the placement is SEARCHED BY MEASUREMENT: candidate arrays are allocated one
+     * after the other and timed together with the arrays already chosen (the skin stage's store pattern, a few ms
+     * each); the candidates not taken are freed before the call returns.  Nothing is assumed about the allocator, and
+     * results never depend on where the arrays are; skinrt_get_output_placement reports what the final measurement
+     * found.  While skinrt_create_crowd runs, the candidates are real allocated memory — up to all of the device's
+     * free memory but 3 GiB, or placement_max_filler_gib — so a concurrent allocation of another thread or
+     * process may fail, and the call takes up to about a second for a 20 GB crowd.
+     * 1: three plain hipMalloc calls, no search, no measurement. */
     uint32_t output_placement;
     /* 1: skinrt_init accepts a library whose skinrt_build_flags() is not 0 (measurement builds). */
     uint32_t allow_experimental_build;
-    /* output_placement = 0: the most the transient filler may reserve, in GiB (0: no limit but the free memory).
-     * When the detour to the next third needs more, the arrays are allocated plainly (strategy 3). */
+    /* output_placement = 0: the most the search may hold in candidates it did not take, in GiB (0: no limit but the
+     * free memory).  When it runs out before a spread placement is found: strategy 3. */
     uint32_t placement_max_filler_gib;
 } skinrt_config;
 
@@ -286,13 +286,13 @@ typedef struct skinrt_section_layout {
  * and for output_placement=1). */
 typedef struct skinrt_placement_info {
     /* 0: plain allocations (small crowd, output_placement = 1, not an MI355X);
-     * 1: steered with filler allocations and the measurement confirms it (spread_gain >= 1.15);
-     * 2: steered, but the arrays did NOT end up spread (spread_gain < 1.15: the allocator did not behave as assumed —
-     *    fragmented or shared memory); they are used as they are, the stage then writes at the one-region rate;
-     * 3: not steered: the detour did not fit the free memory or placement_max_filler_gib; plain allocations, measured. */
+     * 1: placed by the search and the final measurement confirms it (spread_gain >= 1.15);
+     * 2: searched, but no spread placement was found (spread_gain < 1.15: one region reachable, or a device without
+     *    such regions); the arrays are used where they are, the stage then writes at the one-region rate;
+     * 3: the search ran out of room (free memory, placement_max_filler_gib) before it found one. */
     uint32_t strategy;
     uint32_t reserved;
-    uint64_t filler_bytes;      /* transient reservation during skinrt_create_crowd */
+    uint64_t filler_bytes;      /* transient reservation during skinrt_create_crowd (candidates not taken) */
     float probe_together_ms;    /* the skin stage's store pattern, no arithmetic, on all three arrays */
     float probe_alone_ms;       /* the same on the position array alone */
     float spread_gain;          /* 3 * alone / together: ~1.0 = one region, ~1.25-1.3 = spread */

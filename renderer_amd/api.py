@@ -269,7 +269,7 @@ class Crowd:
         """What skinrt_create_crowd did with the output arrays and what it measured."""
         info = PlacementInfo()
         _check(self.ctx.lib.skinrt_get_output_placement(self.handle, C.byref(info)))
-        names = {0: "plain", 1: "steered", 2: "steered-without-effect", 3: "not-steered-no-room"}
+        names = {0: "plain", 1: "spread", 2: "searched-none-found", 3: "search-out-of-room"}
         return {"strategy": names.get(info.strategy, str(info.strategy)), "filler_GiB": info.filler_bytes / 2 ** 30,
                 "probe_together_ms": info.probe_together_ms, "probe_alone_ms": info.probe_alone_ms,
                 "spread_gain": info.spread_gain, "probe_GBps": info.probe_GBps}

@@ -89,6 +89,7 @@ class DeviceBuffers:
         p = C.c_void_p()
         self._ok(self.hip.hipMalloc(C.byref(p), C.c_size_t(max(nbytes, 4))))
         self._ok(self.hip.hipMemset(p, C.c_int(fill), C.c_size_t(max(nbytes, 4))))
+        self._ok(self.hip.hipDeviceSynchronize())  # a memset of device memory returns before it has run
         self.ptrs.append(p)
         return p.value
 
