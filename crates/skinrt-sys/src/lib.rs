@@ -50,6 +50,7 @@ pub const SKINRT_BUILD_STAMPS: u32 = 4;
 pub const SKINRT_BUILD_TUNING: u32 = 8;
 pub const SKINRT_TANGENT_NOALLOC_MAX_VERTICES: u32 = 262_144;
 pub const SKINRT_TANGENT_NOALLOC_MAX_INDICES: u32 = 1_572_864;
+pub const SKINRT_TANGENT_MAX_VALENCE: u32 = 49_152;
 
 #[repr(C)]
 pub struct skinrt_ctx {

@@ -472,7 +472,10 @@ SKINRT_API int skinrt_export_instance_uniform_device(skinrt_crowd* crowd, uint32
  * normalises a zero sum (NaN, as the reference).  positions: host [V][3]; indices: host
  * [index_count] or NULL (then vertices 3f, 3f+1, 3f+2 form triangle f); an index >= V is
  * SKINRT_E_INVALID (reference: panic).  out: host [V][3].  out_device_ms (may be NULL): time of the
- * kernels alone (HIP events), without the transfers. */
+ * kernels alone (HIP events), without the transfers.  A vertex named by more than SKINRT_TANGENT_MAX_VALENCE
+ * triangle corners is SKINRT_E_LIMIT (each vertex's corners are sorted on the device: a few by insertion, up to
+ * that many by heapsort). */
+#define SKINRT_TANGENT_MAX_VALENCE 49152u
 SKINRT_API int skinrt_calculate_tangent(skinrt_ctx* ctx, uint32_t mode, const float* positions, uint32_t vertex_count,
                              const uint32_t* indices, uint32_t index_count, float* out, float* out_device_ms);
 
@@ -484,7 +487,10 @@ SKINRT_API int skinrt_calculate_tangent(skinrt_ctx* ctx, uint32_t mode, const fl
  * SKINRT_TANGENT_NOALLOC_MAX_INDICES corners, else SKINRT_E_LIMIT.  The call enqueues kernels and one
  * hipMemsetAsync on the ctx stream and returns; it calls no hipMalloc / hipFree and does not
  * synchronise (out is defined after skinrt_synchronize).  Every call on a GPU shares that GPU's work
- * area: calls that overlap on one GPU — two ctx on one device, or another thread — race.  The indices
+ * area: calls from several ctx on one GPU are ordered one behind the other on the device (an event made at
+ * skinrt_init; the host does not wait), EXCEPT on a stream under capture, where no event from outside the graph
+ * can be waited for — there, and for anything else that shares the GPU's copy, overlap is the caller's to avoid.
+ * A vertex named by more than SKINRT_TANGENT_MAX_VALENCE corners (which cannot be seen from the host) gets NaN.  The indices
  * cannot be inspected on the host: a triangle with an index >= vertex_count contributes nothing
  * (skinrt_calculate_tangent rejects such input with SKINRT_E_INVALID instead).  Same results, bit for bit,
  * as skinrt_calculate_tangent on valid input. */

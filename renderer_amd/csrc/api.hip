@@ -200,7 +200,7 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg, c
         const uint32_t slots = r.M ? kMorphSlots * kMorphWaveFloats * 4 : 0;
         const uint32_t tables = kSkin2Range * (16 + 24) + p.max_pairs * 16;  // headers, bounds cells, pair records
         // the prologue's scratch (counters, masks, order, run starts, header weights) is overlaid on the wave areas
-        const uint32_t scratch = 32 + kSkin2Range * (4 + 2 + 2 + 8) + 64;
+        const uint32_t scratch = 32 + kSkin2Range * (4 + 2 + 2 + 8 + 8) + 64;
         auto lds_for = [&](uint32_t look) { return tables + std::max(4 * ((look + 1) * 96u * p.jt2 + slots), scratch); };
         // blocks per CU the LDS allows (at most 7: the register budget); two instances of lookahead
         // unless one buys another resident block
@@ -848,6 +848,13 @@ int skinrt_calculate_tangent(skinrt_ctx* ctx, uint32_t mode, const float* positi
     if (indices)
         for (uint32_t k = 0; k < corners; ++k)
             if (indices[k] >= vertex_count) return fail(SKINRT_E_INVALID, "vertex index out of range (reference: index panic)");
+    if (indices && corners > SKINRT_TANGENT_MAX_VALENCE) {  // a vertex named by more corners than the kernels sort: refuse here, where it can be seen
+        std::vector<uint32_t> valence;
+        try { valence.assign(vertex_count, 0u); } catch (const std::bad_alloc&) { return fail(SKINRT_E_NOMEM, "out of host memory"); }
+        for (uint32_t k = 0; k < corners; ++k)
+            if (++valence[indices[k]] > SKINRT_TANGENT_MAX_VALENCE)
+                return fail(SKINRT_E_LIMIT, "a vertex is named by more than SKINRT_TANGENT_MAX_VALENCE triangle corners");
+    }
     HIP_TRY(hipSetDevice(ctx->cfg.device));
     const size_t work_bytes = tangent_work_bytes(vertex_count, corners);
     DevBuf dpos, didx, dwork, dout;
@@ -896,7 +903,13 @@ int skinrt_calculate_tangent_noalloc(skinrt_ctx* ctx, uint32_t mode, const float
         if (e != hipSuccess) return fail(SKINRT_E_DEVICE, std::string("static work area not available on this device: ") + hipGetErrorString(e));
     }
     if (tangent_work_bytes(vertex_count, corners) > work_bytes) return fail(SKINRT_E_LIMIT, "skinrt_calculate_tangent_noalloc: input exceeds the static work area");
-    HIP_TRY(launch_tangents(dev_positions, dev_indices, vertex_count, corners, work, work_bytes, dev_out, ctx->stream));
+    struct Call { const float* pos; const uint32_t* idx; uint32_t v, c; void* work; size_t bytes; float* out; hipStream_t s; } call{
+        dev_positions, dev_indices, vertex_count, corners, work, work_bytes, dev_out, ctx->stream};
+    // several ctx can share one GPU and with it the work area: this call's kernels are ordered behind the previous user's
+    HIP_TRY(tangent_static_use(ctx->cfg.device, ctx->stream, [](void* p) -> hipError_t {
+        const Call& k = *static_cast<const Call*>(p);
+        return launch_tangents(k.pos, k.idx, k.v, k.c, k.work, k.bytes, k.out, k.s);
+    }, &call));
     return SKINRT_OK;
 }
 

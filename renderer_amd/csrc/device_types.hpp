@@ -133,6 +133,8 @@ hipError_t launch_export_skin_uniform(const CrowdDev& cr, uint32_t P, uint32_t j
 size_t tangent_work_bytes(uint32_t vertices, uint32_t corners);
 hipError_t tangent_static_setup(int device);                             // once per device, that device current
 hipError_t tangent_static_area(int device, void** ptr, size_t* bytes);   // the device's copy of the static work area
+// run `launch(arg)` (which enqueues on `s`) as the next user of the device's static work area: ordered behind the previous one
+hipError_t tangent_static_use(int device, hipStream_t s, hipError_t (*launch)(void*), void* arg);
 hipError_t launch_tangents(const float* pos, const uint32_t* indices, uint32_t vertices, uint32_t corners, void* work, size_t work_bytes,
                            float* out, hipStream_t s);
 // placement.hip: the three output arrays, steered over the HBM's regions and measured

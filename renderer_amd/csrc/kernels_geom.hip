@@ -56,18 +56,53 @@ __global__ __launch_bounds__(256) void k_corner_fill(const uint32_t* __restrict_
     adj[start[v] + atomicAdd(&cursor[v], 1u)] = c;
 }
 
-// one thread per vertex: its corners ascending (insertion sort in place: a vertex has a handful),
-// face normals added in that order, then v * (1 / sqrt(dot(v, v))) (tangent.rs:52-56)
+// one thread per vertex: its corners ascending, face normals added in that order, then v * (1 / sqrt(dot(v, v)))
+// (tangent.rs:52-56).  A vertex has a handful of corners: insertion sort in place.  Poles and fans have hundreds to
+// thousands: above kInsertionMax an in-place heapsort, O(n log n) — the quadratic sort was a hang in waiting for a
+// caller's mesh (the device-pointer entry point cannot look at the indices first).  Above
+// SKINRT_TANGENT_MAX_VALENCE corners on ONE vertex (no mesh has that: 16,384 triangles round a point) the vertex is not
+// summed at all and gets NaN, the value the reference gives a vertex it cannot normalise.
+constexpr uint32_t kInsertionMax = 32;
+__device__ void sift_down(uint32_t* a, uint32_t root, uint32_t n) {
+    const uint32_t key = a[root];
+    for (;;) {
+        uint32_t child = 2 * root + 1;
+        if (child >= n) break;
+        uint32_t cv = a[child];
+        if (child + 1 < n) { const uint32_t c2 = a[child + 1]; if (c2 > cv) { cv = c2; ++child; } }
+        if (cv <= key) break;
+        a[root] = cv;
+        root = child;
+    }
+    a[root] = key;
+}
 __global__ __launch_bounds__(256) void k_vertex_sum(uint32_t vertices, const uint32_t* __restrict__ start, uint32_t* __restrict__ adj,
                                                     const float* __restrict__ fn, float* __restrict__ out) {
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     if (v >= vertices) return;
     const uint32_t b = start[v], e = start[v + 1];
-    for (uint32_t i = b + 1; i < e; ++i) {
-        const uint32_t key = adj[i];
-        uint32_t j = i;
-        for (; j > b && adj[j - 1] > key; --j) adj[j] = adj[j - 1];
-        adj[j] = key;
+    if (e - b > SKINRT_TANGENT_MAX_VALENCE) {
+        const float nan = __builtin_nanf("");
+        out[(size_t)v * 3 + 0] = nan; out[(size_t)v * 3 + 1] = nan; out[(size_t)v * 3 + 2] = nan;
+        return;
+    }
+    if (e - b <= kInsertionMax) {
+        for (uint32_t i = b + 1; i < e; ++i) {
+            const uint32_t key = adj[i];
+            uint32_t j = i;
+            for (; j > b && adj[j - 1] > key; --j) adj[j] = adj[j - 1];
+            adj[j] = key;
+        }
+    } else {
+        uint32_t* a = adj + b;
+        const uint32_t n = e - b;
+        for (uint32_t i = n / 2; i-- > 0;) sift_down(a, i, n);
+        for (uint32_t m = n - 1; m > 0; --m) {
+            const uint32_t top = a[0];
+            a[0] = a[m];
+            a[m] = top;
+            sift_down(a, 0, m);
+        }
     }
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
     for (uint32_t i = b; i < e; ++i) {
@@ -137,6 +172,7 @@ std::mutex g_scratch_mutex;
 constexpr int kMaxDevices = 64;
 void* g_scratch_ptr[kMaxDevices];       // device address of `scratch` on each device (nullptr: not resolved)
 hipError_t g_scratch_err[kMaxDevices];  // why not
+hipEvent_t g_scratch_done[kMaxDevices]; // recorded behind the last user of the device's work area (see tangent_static_use)
 
 }  // namespace
 
@@ -151,8 +187,29 @@ hipError_t tangent_static_setup(int device) {
     const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
     g_scratch_err[device] = e;
     if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+    // one event per device, made here so that the entry point itself creates nothing
+    if (hipEventCreateWithFlags(&g_scratch_done[device], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g_scratch_done[device] = nullptr; }
     g_scratch_ptr[device] = ptr;
     return hipSuccess;
+}
+
+// Users of one device's work area, one after the other WITHOUT allocating and without blocking the host: several ctx
+// (streams) may live on one GPU — skinrt_node_create allows a device to be listed more than once — and their calls would
+// race on the shared tables.  `launch` enqueues the user's kernels on `s`; they are ordered behind the previous user's
+// by an event made at set-up.  Under stream capture an event recorded outside the capture cannot be waited for (and
+// one recorded inside it belongs to the graph), so a capturing stream is not chained: overlap is then the caller's
+// business, as skinrt.h says.
+hipError_t tangent_static_use(int device, hipStream_t s, hipError_t (*launch)(void*), void* arg) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    hipEvent_t ev = cap == hipStreamCaptureStatusNone ? g_scratch_done[device] : nullptr;
+    hipError_t e = hipSuccess;
+    if (ev) e = hipStreamWaitEvent(s, ev, 0);  // (an event never recorded counts as complete)
+    if (e == hipSuccess) e = launch(arg);
+    if (e == hipSuccess && ev) e = hipEventRecord(ev, s);
+    return e;
 }
 
 hipError_t tangent_static_area(int device, void** ptr, size_t* bytes) {

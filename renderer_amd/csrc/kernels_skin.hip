@@ -788,31 +788,32 @@ __device__ __forceinline__ void wave_minmax6(float& a0, float& a1, float& a2, fl
 
 
 // Which of a tile's (tile, target) pairs are active for one instance, and whether the self-staging kernel
-// can morph it.  k_skin2 morphs from its two LDS slots only: an instance with 1 or 2 active pairs, both
-// dense, in a tile with at most 32 pairs.  Every other non-idle (tile, instance) is "slow": it goes on the
-// tile's work list (k_classify) and is served by the fix role (fix_role).  k_classify and k_skin2's
-// prologue both call this, so they agree on every (tile, instance).
+// can morph it.  k_skin2 morphs from its two LDS slots per wave only: an instance with 1 or 2 active pairs — dense or
+// compacted (round 3: a compacted pair's region fits a slot as well) — in a tile with at most 32 pairs.  Every other
+// non-idle (tile, instance) is "slow": it goes on the tile's work list (k_classify) and is served by the fix role
+// (fix_role).  k_classify and k_skin2's prologue both call this, so they agree on every (tile, instance).
+// (Round 3 also built the alternative for 3 and more active pairs — k_skin2 morphing them itself IN LINE, two pairs at a
+// time, each wave requesting only the pairs that move its own vertices and waiting for them: bit-identical results, and
+// slower — C3 4.09 -> 4.58 ms, C5 10.6 -> 10.9 ms.  The wait is `vmcnt(0)`, i.e. for every store the wave has in
+// flight, and in a kernel that keeps the HBM write queues full that is many microseconds, which the CU's other waves
+// do not cover; k_skin_fix's waves, running beside k_skin2, have hardly any stores to wait for.  Removed again.)
 struct PairClass {
     uint32_t mask;            // bit min(q, 31) = pair q has a non-zero weight
     bool slow;
-    float w_first, w_second;  // weights of the first two active pairs (set for instances that are not slow)
+    float w_first, w_second;  // weights of the first two active pairs (set for instances with at most two)
 };
 // `active` = the instance's row of CrowdDev::amask (bit t = morph weight t is non-zero), `words` = its length:
 // the np tests read one or two cached 8-byte words instead of np floats scattered over the instance's weight row.
 __device__ __forceinline__ PairClass classify_pairs(const MorphPair* pairs, uint32_t np, const uint64_t* active, uint32_t words, const float* mwg) {
     PairClass pc{0u, false, 0.0f, 0.0f};
     if (np == 0) return pc;  // (rigs without morph targets have no amask at all)
-    uint32_t sparse = 0;
     const uint64_t a0 = active[0];
     for (uint32_t q = 0; q < np; ++q) {
-        const MorphPair mp = pairs[q];
-        const uint32_t t = mp.target;
+        const uint32_t t = pairs[q].target;
         const uint64_t wd = words == 1 ? a0 : active[t >> 6];
-        const uint32_t bit = 1u << min(q, 31u);
-        if ((wd >> (t & 63u)) & 1ull) pc.mask |= bit;
-        if (!mp.dense) sparse |= bit;
+        if ((wd >> (t & 63u)) & 1ull) pc.mask |= 1u << min(q, 31u);
     }
-    pc.slow = pc.mask != 0 && (np > 32 || __popc(pc.mask) > 2 || (pc.mask & sparse) != 0);
+    pc.slow = pc.mask != 0 && (np > 32 || __popc(pc.mask) > 2);
     if (SKINRT_ABLATE & 4) { pc.slow = false; pc.mask = 0; }
     if (pc.mask != 0 && !pc.slow) {  // at most two active pairs, np <= 32: their weights go into the instance's header
         const uint32_t q1 = (uint32_t)__ffs((int)pc.mask) - 1;
@@ -1086,6 +1087,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     uint16_t* perm_s = reinterpret_cast<uint16_t*>(mask_s + kSkin2Range);       // [range] sorted order
     uint16_t* start_s = perm_s + kSkin2Range;                                   // [runs] sorted position where run j starts
     float2* w12_s = reinterpret_cast<float2*>(start_s + kSkin2Range);           // [range] weights of the first two active pairs
+    uint64_t* key_s = reinterpret_cast<uint64_t*>(w12_s + kSkin2Range);         // [range] sort keys (class, mask, rotated index)
     const uint32_t pal_slot_f = JTP * 24;                                       // floats per palette slot
     const uint32_t per_wave_f = R * pal_slot_f + (M ? kMorphSlots * kMorphWaveFloats : 0u);
     float* pal_ring = wave_s + (size_t)wave * per_wave_f;                       // [R][JTP][6] f4
@@ -1104,28 +1106,26 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     // pairs that move at least one of THIS wave's 64 vertices (bit q, first 32 pairs): the others are
     // neither requested nor applied by this wave (their deltas here are all zero)
     const uint32_t my_pairs = (uint32_t)__ballot(lane < min(np, 32u) && ((pairs_s[min(lane, np ? np - 1 : 0u)].wave_mask >> wave) & 1u));
-    // active-pair mask of instance-in-range `tid` (bit min(q, 31) = pair q has a non-zero weight).
-    // This kernel morphs from its two LDS slots only: an instance with 1 or 2 active pairs, both
-    // dense.  Every other non-idle (tile, instance) — 3+ active pairs, a compacted pair, a tile with
-    // more than 32 pairs — goes on the work list of k_skin_fix and is left out of this block's order.
-    uint32_t my_mask = 0xffffffffu;  // padding and handed-over instances sort last
+    // active-pair mask of instance-in-range `tid` (bit min(q, 31) = pair q has a non-zero weight) and its class:
+    // 0 idle, 1 fast (1 or 2 active pairs: the LDS slots, requested ahead), 3 handed over (3 or more active pairs, or a
+    // tile with more than 32 pairs: on the work list of k_skin_fix already) or padding.  Classes 0 and 1 are this block's.
+    uint32_t my_mask = 0xffffffffu, my_cls = 3u;
     {
-        bool slow = false;
         float w_first = 0.0f, w_second = 0.0f;
         if (tid < nin) {
             const uint32_t words = (M + 63) / 64;
             const PairClass pc = classify_pairs(pairs_s, np, cr.amask + (size_t)(i0 + tid) * words, words, cr.mw + (size_t)(i0 + tid) * M);
-            slow = pc.slow;
-            my_mask = slow ? 0xffffffffu : pc.mask;  // slow: on the tile's work list already (k_classify)
+            my_mask = pc.mask;
+            my_cls = pc.slow ? 3u : (pc.mask == 0 ? 0u : 1u);
             w_first = pc.w_first;
             w_second = pc.w_second;
         }
-        const uint64_t bslow = __ballot(slow);
-        if (lane == 0 && wave < 2) cnt_s[4 + wave] = (uint32_t)__popcll(bslow);
+        const uint64_t bfast = __ballot(my_cls <= 1u);
+        if (lane == 0 && wave < 2) cnt_s[4 + wave] = (uint32_t)__popcll(bfast);
         if (tid < kSkin2Range) { mask_s[tid] = my_mask; w12_s[tid] = make_float2(w_first, w_second); }
     }
     __syncthreads();
-    const uint32_t nproc = nin - cnt_s[4] - cnt_s[5];  // instances this block processes itself
+    const uint32_t nproc = cnt_s[4] + cnt_s[5];  // instances this block processes itself (idle + fast)
     // processing order: equal masks become neighbours (rank sort on distinct (mask, index) keys)
     if (tid < kSkin2Range) {
         // Ties are broken by the instance's index ROTATED by a tile-dependent amount: neighbouring tiles then walk a
@@ -1137,15 +1137,17 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
         // (Starting the block's four WAVES at different points of the order as well: slower, 3.9 -> 4.1 ms ablated — the
         // waves' four 768-byte pieces of an instance row want to be written together.)
         const uint32_t rot = nin ? (tile * SKINRT_ORDER_ROT) % nin : 0u;
-        auto key = [&](uint32_t x) { return x < nin ? (x + rot < nin ? x + rot : x + rot - nin) : x; };
-        const uint32_t my_key = key(tid);
+        const uint32_t rkey = tid < nin ? (tid + rot < nin ? tid + rot : tid + rot - nin) : tid;
+        // one 64-bit key per instance: class, then mask, then rotated index (all keys distinct)
+        key_s[tid] = ((uint64_t)my_cls << 40) | ((uint64_t)my_mask << 8) | rkey;
+    }
+    __syncthreads();
+    if (tid < kSkin2Range) {
+        const uint64_t mine = key_s[tid];
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < kSkin2Range; j += 4) {
-            const uint4 mj = *reinterpret_cast<const uint4*>(mask_s + j);
-            rank += (mj.x < my_mask || (mj.x == my_mask && key(j + 0) < my_key)) ? 1u : 0u;
-            rank += (mj.y < my_mask || (mj.y == my_mask && key(j + 1) < my_key)) ? 1u : 0u;
-            rank += (mj.z < my_mask || (mj.z == my_mask && key(j + 2) < my_key)) ? 1u : 0u;
-            rank += (mj.w < my_mask || (mj.w == my_mask && key(j + 3) < my_key)) ? 1u : 0u;
+        for (uint32_t j = 0; j < kSkin2Range; j += 2) {
+            const ulonglong2 kj = *reinterpret_cast<const ulonglong2*>(key_s + j);
+            rank += (kj.x < mine ? 1u : 0u) + (kj.y < mine ? 1u : 0u);
         }
         perm_s[rank] = (uint16_t)tid;
     }
@@ -1177,7 +1179,8 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     __syncthreads();
     // header of one instance, written at its processing position:
     //   x = active pairs (0, 1 or 2) | near << 8 | prefetch << 10 | pairs to prefetch << 11 |
-    //       first pair << 16 | second << 24;   y = instance;   z, w = weights of those two pairs
+    //       first pair compacted << 13 | second compacted << 14 | first pair << 16 | second << 24;
+    //   y = instance;   z, w = weights of those two pairs
     // near: its pairs are requested during the previous instance; prefetch (idle instances only):
     // request the named pairs, which belong to the run after this spacer.
     if (in_range) {
@@ -1208,8 +1211,9 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
                 w2 = na >= 2 ? w12.y : w12.x;  // one active pair: both header weights name it (as q2 = q1)
             }
         }
+        const uint32_t sparse12 = na ? ((pairs_s[q1].dense ? 0u : 1u) << 13) | ((pairs_s[q2].dense ? 0u : 1u) << 14) : 0u;
         const uint32_t x = pf ? ((1u << 10) | (na << 11) | (q1 << 16) | (q2 << 24))
-                              : (na | (near << 8) | (q1 << 16) | (q2 << 24));
+                              : (na | (near << 8) | sparse12 | (q1 << 16) | (q2 << 24));
         hdr_s[fpos] = make_uint4(x, inst, __float_as_uint(w1), __float_as_uint(w2));
     }
     // this thread's vertex
@@ -1300,6 +1304,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
         const uint32_t na = (SKINRT_ABLATE & 1) ? 0u : (hx & 0xffu);
         const bool reload = ((hx >> 8) & 1u) != 0;
         const float mw1 = __uint_as_float(hz), mw2 = __uint_as_float(hw);
+        const bool dense1 = ((hx >> 13) & 1u) == 0, dense2 = ((hx >> 14) & 1u) == 0;
         const size_t obase = (size_t)i * rig.V * 3;
         // (1) wait: this instance's palette was requested L instances ago and every instance since
         // issued at least spi stores; its morph pairs (if they had to be reloaded) were requested
@@ -1320,8 +1325,8 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
         // (3) morph (a13): p = p0 + sum_m w_m * delta_m, targets ascending
         float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
         if (na) {
-            if ((my_pairs >> ((hx >> 16) & 0xffu)) & 1u) morph_pair<EXACT>(my_slots, true, tid, mw1, p, n, t);
-            if (na >= 2 && ((my_pairs >> (hx >> 24)) & 1u)) morph_pair<EXACT>(my_slots + kMorphWaveFloats, true, tid, mw2, p, n, t);
+            if ((my_pairs >> ((hx >> 16) & 0xffu)) & 1u) morph_pair<EXACT>(my_slots, dense1, tid, mw1, p, n, t);
+            if (na >= 2 && ((my_pairs >> (hx >> 24)) & 1u)) morph_pair<EXACT>(my_slots + kMorphWaveFloats, dense2, tid, mw2, p, n, t);
         }
         // (4) position
         float op[3];
@@ -1449,7 +1454,10 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         // stores, 5 KiB of LDS) on the side stream fits into the wave slots, registers and LDS that k_skin2's five
         // blocks per CU leave free, so it costs the stage almost nothing; one after the other it costs its full
         // 0.5 ms (C3).  Fork / join by events: the caller's stream sees the stage as one unit.
-        const bool side = cr.fix && conc.side != nullptr && conc.fork != nullptr && conc.join != nullptr;
+        // (a tile needs at least 3 pairs to hand an instance over: without such a tile there is no list to build and no
+        // k_skin_fix to launch; the active-pair bit rows are k_skin2's own input either way)
+        const bool lists = cr.fix && plan.max_pairs > 2;
+        const bool side = lists && conc.side != nullptr && conc.fork != nullptr && conc.join != nullptr;
         if (cr.fix) {
             e = hipMemsetAsync(cr.fix, 0, (size_t)rig.T * 4, s);  // empty work lists
             if (e != hipSuccess) return e;
@@ -1458,7 +1466,7 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
             const uint32_t words = (rig.M + 63) / 64;
             if (!cr.amask || (uint64_t)cr.I * words > 0x7fffffffull) return hipErrorInvalidValue;
             hipLaunchKernelGGL(k_active_mask, dim3((cr.I * words + 3) / 4), dim3(256), 0, s, cr, rig.M, words);
-            hipLaunchKernelGGL(k_classify, dim3(rig.T * slices), dim3(256), 0, s, rig, cr, slices, words);
+            if (lists) hipLaunchKernelGGL(k_classify, dim3(rig.T * slices), dim3(256), 0, s, rig, cr, slices, words);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             if (side && (e = hipEventRecord(conc.fork, s)) != hipSuccess) return e;  // the lists are complete here
@@ -1490,7 +1498,7 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
             if (side) return hipEventRecord(conc.join, conc.side);
             return hipSuccess;
         };
-        const bool want_fix = cr.fix && !(SKINRT_ABLATE & 32);
+        const bool want_fix = lists && !(SKINRT_ABLATE & 32);
         if (want_fix && !conc.skin2_first && (e = launch_fix()) != hipSuccess) return e;
         const dim3 grid(8u * plan.tiles_per_chunk2 * plan.ranges_per_chunk2), block(kSkin2Threads);
 #define SKINRT_LAUNCH2(EX, KK, LL, SK) hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK>), grid, block, plan.lds_bytes2, s, rig, cr, plan)

@@ -70,6 +70,32 @@ def test_high_valence_and_repeated_corners(oracle32):
     assert np.array_equal(bits(got), bits(want))
 
 
+def _fan(k, rng):
+    ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+    pos = np.concatenate([[[0, 0, 1]], np.stack([np.cos(ang), np.sin(ang), rng.normal(scale=0.2, size=k)], 1)]).astype(np.float32)
+    fan = np.stack([np.zeros(k, np.int64), 1 + np.arange(k), 1 + (np.arange(k) + 1) % k], 1)
+    rng.shuffle(fan)
+    return pos, fan.astype(np.uint32).reshape(-1)
+
+
+def test_a_pole_of_thousands_of_triangles_is_sorted_in_n_log_n(oracle32):
+    """the per-vertex corner sort was quadratic.  A pole with 12,000 triangles (its vertex is named by 12,000
+    corners, every rim vertex by two) goes through the heapsort branch and still adds its normals in the sequential
+    loop's order: bit-equal.  More corners on one vertex than SKINRT_TANGENT_MAX_VALENCE is refused where it can be seen."""
+    rng = np.random.default_rng(8)
+    pos, idx = _fan(12000, rng)
+    with api.Context() as ctx:
+        got, ms = ctx.calculate_tangent(TRIANGLE_LIST, pos, idx, with_ms=True)
+        want = oracle32.calculate_tangent(TRIANGLE_LIST, pos, idx)
+        assert np.array_equal(bits(got), bits(want))
+        print(f"[tangent] pole of 12,000 triangles: kernels {ms:.2f} ms")
+        assert ms < 2000.0
+        big_pos, big_idx = _fan(49152 + 1, rng)
+        with pytest.raises(api.SkinrtError) as e:
+            ctx.calculate_tangent(TRIANGLE_LIST, big_pos, big_idx)
+        assert e.value.code == abi.E_LIMIT and "SKINRT_TANGENT_MAX_VALENCE" in e.value.message
+
+
 def test_modes_and_errors():
     pos = np.eye(3, dtype=np.float32)
     with api.Context() as ctx:
