@@ -245,6 +245,8 @@ def main():
     ap.add_argument("--instances", type=int, default=None, help="override the TOTAL instance count")
     ap.add_argument("--no-vertex-gather", action="store_true", help="N>1: skip the extra vertex all-gather measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed region: no clock-advancing loop, no plain-placement crowd, no copy / fill rates (profiling runs)")
     ap.add_argument("--advance-clocks", action="store_true",
                     help="every timed frame also advances the instances' clocks on the device (skinrt_advance_clocks, 1/60 s): the frame "
                          "a renderer's loop runs; without it the loop is timed after the main region and reported as frame_loop")
@@ -350,7 +352,7 @@ def main():
     # What a renderer's loop does per frame: new inputs, then the frame.  The clocks advance ON THE DEVICE, stream-ordered
     # (skinrt_advance_clocks): nothing drains the GPU between frames.  Measured next to the plain frame.
     frame_loop = None
-    if not args.advance_clocks:
+    if not args.advance_clocks and not args.no_extras:
         n_loop = min(args.steps, 30)
         dt_adv = loop.timed(n_loop, advance=True)
         dt_same = loop.timed(n_loop, advance=False)
@@ -361,7 +363,7 @@ def main():
     # The same frames with the three output arrays where three plain hipMalloc calls put them (no steering over the HBM's
     # thirds): what the kernels do without placement.hip.  A second context + crowd, N = 1 only.
     plain_ms = None
-    if n_gpus == 1 and crowd.placement["strategy"] != "plain":
+    if n_gpus == 1 and crowd.placement["strategy"] != "plain" and not args.no_extras:
         try:
             ctx2 = api.Context(device=local_rank, exact_arithmetic=args.exact, output_placement=1)
             rig2 = api.Rig(ctx2, rig_data)
@@ -432,6 +434,8 @@ def main():
         try:
             if n_gpus != 1:
                 raise RuntimeError("measured at N=1 only")
+            if args.no_extras:
+                raise RuntimeError("--no-extras")
             bw = measured_bandwidth(local_rank)
             out["roofline"]["measured_GBps"] = {"d2d_copy_read_plus_write": bw["d2d_copy"], "fill_write_only": bw["fill"]}
             out["roofline"]["frac_of_measured_copy"] = (achieved / 1e9) / bw["d2d_copy"]

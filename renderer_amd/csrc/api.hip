@@ -361,6 +361,10 @@ int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig**
     d.levels = h.levels; d.T = h.T;
     d.weight_channel_clips = h.weight_channel_clips;
     d.skip_sets = h.skip_sets ? 1u : 0u;
+    d.sparse_pairs = 0;
+    if (SKINRT_SPARSE_SLOTS)
+        for (const MorphPair& mp : h.pairs)
+            if (!mp.dense) { d.sparse_pairs = 1; break; }
     if (ctx->env.skip_sets >= 0) d.skip_sets = (h.K == 2 && ctx->env.skip_sets != 0) ? 1u : 0u;  // tools/exp_skip_sets.py
     const float* defw = nullptr;
 #define UP(field) if ((rc = upload(r, h.field, &d.field)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }

@@ -37,6 +37,7 @@ struct RigDev {
     const MorphPair* pairs;
     const float* mblock;
     uint32_t skip_sets;  // CompiledRig::skip_sets
+    uint32_t sparse_pairs;  // the rig has compacted (tile, target) pairs and k_skin2 takes them from its slots (its SPARSE instantiations)
 };
 
 // Per-crowd state and outputs (HBM layout: DESIGN.md §3).

@@ -63,6 +63,13 @@ __device__ unsigned long long g_stamps[16];
 #ifndef SKINRT_EXP
 #define SKINRT_EXP 0
 #endif
+// 1 (the product): on rigs that have compacted pairs, k_skin2 takes them from its LDS slots too (its SPARSE
+// instantiations); 0: it hands every instance with an active compacted pair to k_skin_fix, as until round 2 (A/B
+// builds; same results).  Rigs whose pairs are all dense run the dense-only instantiations either way: carrying the
+// per-pair layout flag through the instance loop costs them 2.5 % (C3) to 6 % (C5) of the stage (profiles/r03_ubench.txt).
+#ifndef SKINRT_SPARSE_SLOTS
+#define SKINRT_SPARSE_SLOTS 1
+#endif
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -804,16 +811,21 @@ struct PairClass {
 };
 // `active` = the instance's row of CrowdDev::amask (bit t = morph weight t is non-zero), `words` = its length:
 // the np tests read one or two cached 8-byte words instead of np floats scattered over the instance's weight row.
-__device__ __forceinline__ PairClass classify_pairs(const MorphPair* pairs, uint32_t np, const uint64_t* active, uint32_t words, const float* mwg) {
+// sparse_ok: compacted pairs may sit in k_skin2's slots (RigDev::sparse_pairs: the rig has some and runs the SPARSE instantiations)
+__device__ __forceinline__ PairClass classify_pairs(const MorphPair* pairs, uint32_t np, const uint64_t* active, uint32_t words, const float* mwg,
+                                                    bool sparse_ok) {
     PairClass pc{0u, false, 0.0f, 0.0f};
     if (np == 0) return pc;  // (rigs without morph targets have no amask at all)
     const uint64_t a0 = active[0];
+    uint32_t sparse = 0;
     for (uint32_t q = 0; q < np; ++q) {
-        const uint32_t t = pairs[q].target;
+        const MorphPair mp = pairs[q];
+        const uint32_t t = mp.target;
         const uint64_t wd = words == 1 ? a0 : active[t >> 6];
         if ((wd >> (t & 63u)) & 1ull) pc.mask |= 1u << min(q, 31u);
+        if (!sparse_ok && !mp.dense) sparse |= 1u << min(q, 31u);
     }
-    pc.slow = pc.mask != 0 && (np > 32 || __popc(pc.mask) > 2);
+    pc.slow = pc.mask != 0 && (np > 32 || __popc(pc.mask) > 2 || (pc.mask & sparse) != 0);
     if (SKINRT_ABLATE & 4) { pc.slow = false; pc.mask = 0; }
     if (pc.mask != 0 && !pc.slow) {  // at most two active pairs, np <= 32: their weights go into the instance's header
         const uint32_t q1 = (uint32_t)__ffs((int)pc.mask) - 1;
@@ -861,7 +873,7 @@ __global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdD
     for (uint32_t r = 0; r < kClassifyRounds; ++r) {
         const uint32_t inst = i0 + r * 256u + tid;
         bool slow = false;
-        if (inst < cr.I) slow = classify_pairs(rig.pairs + pbeg, np, cr.amask + (size_t)inst * words, words, cr.mw + (size_t)inst * rig.M).slow;
+        if (inst < cr.I) slow = classify_pairs(rig.pairs + pbeg, np, cr.amask + (size_t)inst * words, words, cr.mw + (size_t)inst * rig.M, rig.sparse_pairs != 0).slow;
         const uint64_t bslow = __ballot(slow);
         if (lane == 0) wave_n[r * 4 + wave] = (uint32_t)__popcll(bslow);
         rank[r] = (uint32_t)__popcll(bslow & ((1ull << lane) - 1ull));
@@ -1051,7 +1063,7 @@ __device__ __forceinline__ float wave_bounds_packed(const float (&v)[3], bool up
 
 constexpr uint32_t kSkin2Threads = 256;
 
-template <int AR, int K, int LOOK, bool SKIP>
+template <int AR, int K, int LOOK, bool SKIP, bool SPARSE>
 __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) void k_skin2(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
     constexpr uint32_t TV = kTileVerts;
@@ -1114,7 +1126,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
         float w_first = 0.0f, w_second = 0.0f;
         if (tid < nin) {
             const uint32_t words = (M + 63) / 64;
-            const PairClass pc = classify_pairs(pairs_s, np, cr.amask + (size_t)(i0 + tid) * words, words, cr.mw + (size_t)(i0 + tid) * M);
+            const PairClass pc = classify_pairs(pairs_s, np, cr.amask + (size_t)(i0 + tid) * words, words, cr.mw + (size_t)(i0 + tid) * M, SPARSE);
             my_mask = pc.mask;
             my_cls = pc.slow ? 3u : (pc.mask == 0 ? 0u : 1u);
             w_first = pc.w_first;
@@ -1304,7 +1316,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
         const uint32_t na = (SKINRT_ABLATE & 1) ? 0u : (hx & 0xffu);
         const bool reload = ((hx >> 8) & 1u) != 0;
         const float mw1 = __uint_as_float(hz), mw2 = __uint_as_float(hw);
-        const bool dense1 = ((hx >> 13) & 1u) == 0, dense2 = ((hx >> 14) & 1u) == 0;
+        const bool dense1 = !SPARSE || ((hx >> 13) & 1u) == 0, dense2 = !SPARSE || ((hx >> 14) & 1u) == 0;
         const size_t obase = (size_t)i * rig.V * 3;
         // (1) wait: this instance's palette was requested L instances ago and every instance since
         // issued at least spi stores; its morph pairs (if they had to be reloaded) were requested
@@ -1501,7 +1513,11 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         const bool want_fix = lists && !(SKINRT_ABLATE & 32);
         if (want_fix && !conc.skin2_first && (e = launch_fix()) != hipSuccess) return e;
         const dim3 grid(8u * plan.tiles_per_chunk2 * plan.ranges_per_chunk2), block(kSkin2Threads);
-#define SKINRT_LAUNCH2(EX, KK, LL, SK) hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK>), grid, block, plan.lds_bytes2, s, rig, cr, plan)
+#define SKINRT_LAUNCH2(EX, KK, LL, SK)                                                                                     \
+    do {                                                                                                                   \
+        if (rig.sparse_pairs) hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, true>), grid, block, plan.lds_bytes2, s, rig, cr, plan); \
+        else hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, false>), grid, block, plan.lds_bytes2, s, rig, cr, plan);          \
+    } while (0)
 #define SKINRT_LAUNCH2K(EX, LL)                                                            \
     do {                                                                                   \
         if (rig.K == 1) SKINRT_LAUNCH2(EX, 1, LL, false);                                  \
@@ -1555,7 +1571,7 @@ uint32_t skin_build_flags() {
     f |= SKINRT_BUILD_STAMPS;
 #endif
     if (SKINRT_RANGE2 != 80 || SKINRT_MORPH_SLOTS != 2 || SKINRT_INFLIGHT != 2 || SKINRT_BLOCKS_K1 != 5 || SKINRT_ORDER_ROT != 23u ||
-        SKINRT_STORE_POLICY != 1 || sizeof(SKINRT_PAL_MOD) != 1)
+        SKINRT_STORE_POLICY != 1 || sizeof(SKINRT_PAL_MOD) != 1 || SKINRT_SPARSE_SLOTS != 1)
         f |= SKINRT_BUILD_TUNING;
     return f;
 }

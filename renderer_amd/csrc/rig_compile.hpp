@@ -46,6 +46,9 @@ constexpr uint32_t kSkin2Range = SKINRT_RANGE2;         // instances per block o
 constexpr uint32_t kMorphWaveFloats = 576;    // one wave's share of a dense pair = one LDS slot
 constexpr uint32_t kMorphDenseMin = 57;       // touched vertices from which a pair is stored dense
                                               // (a sparse region, 64 + 56*9 floats, still fits a slot)
+#ifndef SKINRT_SPARSE_SLOTS
+#define SKINRT_SPARSE_SLOTS 1  // see kernels_skin.hip
+#endif
 #ifndef SKINRT_MORPH_SLOTS
 #define SKINRT_MORPH_SLOTS 2
 #endif

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 R=$PWD
 run() { # name, rocprof args
   local name=$1; shift
-  timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d $R/$OUT/$name -- python3 $R/bench.py $ARGS --no-cpu-baseline > $R/$OUT/$name.log 2>&1 || { echo "$name failed"; tail -5 $R/$OUT/$name.log; return 1; }
+  timeout -s KILL 240 rocprofv3 "$@" --output-format csv -d $R/$OUT/$name -- python3 $R/bench.py $ARGS --no-cpu-baseline --no-extras > $R/$OUT/$name.log 2>&1 || { echo "$name failed"; tail -5 $R/$OUT/$name.log; return 1; }
 }
 run trace --kernel-trace --stats || exit 1
 run pmc1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS || exit 1
