@@ -2,6 +2,11 @@
 //! repository); this is where the path's node order is fixed: DFS pre-order over `SceneAsset.nodes`, then
 //! children, in file order (the trees come from load_node / load_scene, renderer-asset/src/loader/gltf/mod.rs:1168-1217).
 //!
+//! Every node with a mesh becomes a SECTION of the rig's vertex array (its primitives concatenated); a section names
+//! the node's skin (distinct `SkinAsset`s by id, in the order they are met) or none — an un-skinned mesh node is drawn
+//! with its world matrix (`InstanceUniform`, shader.wgsl:143-152), which the library evaluates through a pseudo-joint.
+//! Morph targets, default weights and `weights` channels belong to a section (include/skinrt.h, `skinrt_section_desc`).
+//!
 //! Types consumed (fifth-light/renderer, crates/renderer-asset/src): node.rs:89-99 (`NodeAsset`), :9-33
 //! (`NodeTransform`), skin.rs:5-11 (`SkinAsset`), animation.rs:8-40, primitive.rs:22-38, mesh.rs:3-8.
 use std::collections::BTreeMap;
@@ -27,8 +32,16 @@ pub struct FlatChannel {
 }
 
 #[derive(Debug, Clone, Default)]
+pub struct FlatSkin {
+    pub id: Option<AssetIndex>,
+    pub joint_node: Vec<u32>,
+    /// empty = identity (loader/gltf/mod.rs:1139-1145)
+    pub inverse_bind: Vec<f32>,
+}
+
+#[derive(Debug, Clone, Default)]
 pub struct FlatTarget {
-    /// empty: dense (count == vertex_count)
+    /// not dense: rows of the SECTION (counted from its first vertex) the deltas belong to
     pub indices: Vec<u32>,
     pub dense: bool,
     pub position: Vec<f32>,
@@ -46,9 +59,10 @@ pub struct FlatRig {
     pub scale: Vec<f32>,
     pub matrix: Vec<f32>,
     pub has_matrix: Vec<u8>,
-    pub joint_node: Vec<u32>,
-    /// empty = identity (loader/gltf/mod.rs:1139-1145)
-    pub inverse_bind: Vec<f32>,
+    /// distinct skins in the order the walk meets them (a8)
+    pub skins: Vec<FlatSkin>,
+    /// one per mesh node, DFS order; they tile the vertex array and the target list
+    pub sections: Vec<sys::skinrt_section_desc>,
     pub clips: Vec<Vec<FlatChannel>>,
     /// max over channels of `AnimationChannelAsset::length`
     pub clip_length: Vec<f32>,
@@ -64,11 +78,30 @@ pub struct FlatRig {
     pub sanitized_tangent_deltas: u64,
 }
 
+/// What to take from the scenes (the defaults: everything).
+#[derive(Debug, Clone)]
+pub struct FlattenOptions {
+    /// `None` = every scene in order
+    pub scene: Option<usize>,
+    /// only the mesh nodes bound to this skin (one-skin rigs, as before ABI 6)
+    pub skin: Option<AssetIndex>,
+    /// mesh nodes without a skin become un-skinned sections
+    pub include_unskinned: bool,
+}
+
+impl Default for FlattenOptions {
+    fn default() -> Self {
+        Self { scene: None, skin: None, include_unskinned: true }
+    }
+}
+
 struct Walk<'r, 'a> {
     rig: &'r mut FlatRig,
     index_of: BTreeMap<AssetIndex, u32>,
-    skinned: Vec<(u32, &'a NodeAsset)>,
-    skin: Option<Arc<SkinAsset>>,
+    /// (node index, node, skin index or -1)
+    meshes: Vec<(u32, &'a NodeAsset, i32)>,
+    skins: Vec<Arc<SkinAsset>>,
+    opt: &'a FlattenOptions,
 }
 
 impl<'r, 'a> Walk<'r, 'a> {
@@ -99,13 +132,22 @@ impl<'r, 'a> Walk<'r, 'a> {
         self.rig.scale.extend_from_slice(&s);
         self.rig.matrix.extend_from_slice(&m);
         self.rig.has_matrix.push(is_matrix);
-        if let (Some(skin), Some(_)) = (&n.skin, &n.mesh) {
-            if self.skin.is_none() {
-                self.skin = Some(skin.clone());
+        match (&n.mesh, &n.skin) {
+            // node.rs:95-96: the node names its skin (shared by Arc, cached per glTF skin: loader/gltf/mod.rs:1124-1128)
+            (Some(_), Some(skin)) => {
+                if self.opt.skin.as_ref().map(|want| *want == skin.id).unwrap_or(true) {
+                    let k = match self.skins.iter().position(|s| s.id == skin.id) {
+                        Some(k) => k,
+                        None => {
+                            self.skins.push(skin.clone());
+                            self.skins.len() - 1
+                        }
+                    };
+                    self.meshes.push((me, n, k as i32));
+                }
             }
-            if self.skin.as_ref().map(|s| s.id == skin.id).unwrap_or(false) {
-                self.skinned.push((me, n));
-            }
+            (Some(_), None) if self.opt.skin.is_none() && self.opt.include_unskinned => self.meshes.push((me, n, -1)),
+            _ => {}
         }
         for c in &n.children {
             self.node(c, me as i32);
@@ -135,25 +177,29 @@ fn push_keys<V: AsRef<[f32]> + std::fmt::Debug + Clone>(k: &AnimationKeyFrames<V
     }
 }
 
-/// `scene`: `None` = every scene in order.
+/// `scene`: `None` = every scene in order; every skin and every mesh node (see [`FlattenOptions`] for less).
 pub fn flatten(scenes: &[SceneAsset], animations: &[AnimationAsset], scene: Option<usize>) -> Result<FlatRig, Error> {
+    flatten_with(scenes, animations, &FlattenOptions { scene, ..Default::default() })
+}
+
+pub fn flatten_with(scenes: &[SceneAsset], animations: &[AnimationAsset], opt: &FlattenOptions) -> Result<FlatRig, Error> {
     let mut rig = FlatRig::default();
-    if let Some(s) = scene {
+    if let Some(s) = opt.scene {
         if s >= scenes.len() {
             return Err(Error::new(sys::SKINRT_E_RANGE, "scene index out of range"));
         }
     }
-    let (index_of, skinned, skin) = {
-        let mut w = Walk { rig: &mut rig, index_of: BTreeMap::new(), skinned: Vec::new(), skin: None };
+    let (index_of, meshes, skins) = {
+        let mut w = Walk { rig: &mut rig, index_of: BTreeMap::new(), meshes: Vec::new(), skins: Vec::new(), opt };
         for (k, sc) in scenes.iter().enumerate() {
-            if scene.map(|s| s != k).unwrap_or(false) {
+            if opt.scene.map(|s| s != k).unwrap_or(false) {
                 continue;
             }
             for n in &sc.nodes {
                 w.node(n, -1);
             }
         }
-        (w.index_of, w.skinned, w.skin)
+        (w.index_of, w.meshes, w.skins)
     };
     if rig.parent.is_empty() {
         return Err(Error::new(sys::SKINRT_E_INVALID, "no nodes"));
@@ -162,20 +208,22 @@ pub fn flatten(scenes: &[SceneAsset], animations: &[AnimationAsset], scene: Opti
         rig.matrix.clear();
         rig.has_matrix.clear();
     }
-    // skin: joint -> node, inverse bind matrices (a8)
-    if let Some(skin) = &skin {
+    // skins: joint -> node, inverse bind matrices (a8)
+    for skin in &skins {
+        let mut fs = FlatSkin { id: Some(skin.id.clone()), ..Default::default() };
         for j in &skin.joint_ids {
             let n = index_of.get(j).ok_or_else(|| Error::new(sys::SKINRT_E_RANGE, "skin joint id is not a node of the flattened scenes"))?;
-            rig.joint_node.push(*n);
+            fs.joint_node.push(*n);
         }
         if !skin.inverse_bind_matrices.is_empty() {
             if skin.inverse_bind_matrices.len() != skin.joint_ids.len() {
                 return Err(Error::new(sys::SKINRT_E_INVALID, "inverse_bind_matrices length != joint_ids length"));
             }
             for m in &skin.inverse_bind_matrices {
-                rig.inverse_bind.extend_from_slice(&m.to_cols_array());
+                fs.inverse_bind.extend_from_slice(&m.to_cols_array());
             }
         }
+        rig.skins.push(fs);
     }
     // clips (a1): one per AnimationAsset, channels in file order
     for a in animations {
@@ -198,7 +246,9 @@ pub fn flatten(scenes: &[SceneAsset], animations: &[AnimationAsset], scene: Opti
                     push_keys(k, &mut ch);
                 }
                 // A MorphTargetWeights(AnimationKeyFrames<Vec<f32>>) variant — the reference's loader stops at todo!()
-                // for it (loader/gltf/mod.rs:1312) — maps to SKINRT_PATH_WEIGHTS with the same push_keys call.
+                // for it (loader/gltf/mod.rs:1312) — maps to SKINRT_PATH_WEIGHTS with the same push_keys call; the
+                // channel then belongs to the section on its target node and carries that section's target count
+                // per key (checked at the end of flatten.cpp; the same check goes here with the variant).
             }
             length = length.max(c.length);
             clip.push(ch);
@@ -206,46 +256,55 @@ pub fn flatten(scenes: &[SceneAsset], animations: &[AnimationAsset], scene: Opti
         rig.clips.push(clip);
         rig.clip_length.push(length);
     }
-    // mesh (a11, a13): primitives of the nodes that use the skin, concatenated in DFS order
+    // mesh (a11, a13): one section per mesh node, its primitives concatenated; the morph targets of a section are its
+    // MeshAsset's (every primitive of a glTF mesh carries the same number of targets, weights live on the mesh: mesh.rs:4-8)
     let mut k_sets = 0usize;
-    let mut m_targets = 0usize;
-    let mut prims = 0usize;
-    for (_, n) in &skinned {
-        for p in &n.mesh.as_ref().unwrap().primitives {
-            k_sets = k_sets.max(p.attributes.joints.len().min(p.attributes.weights.len()));
-            m_targets = m_targets.max(p.targets.len());
-            prims += 1;
+    for (_, n, skin) in &meshes {
+        if *skin >= 0 {
+            for p in &n.mesh.as_ref().unwrap().primitives {
+                k_sets = k_sets.max(p.attributes.joints.len().min(p.attributes.weights.len()));
+            }
         }
     }
-    let k_sets = k_sets.max(1);
+    if k_sets > 4 {
+        return Err(Error::new(sys::SKINRT_E_LIMIT, "more than 4 joint/weight sets"));
+    }
+    if k_sets == 0 && !meshes.is_empty() {
+        k_sets = 1; // un-skinned meshes only: one (unread) set keeps the descriptor regular
+    }
     rig.joints = vec![Vec::new(); k_sets];
     rig.weights = vec![Vec::new(); k_sets];
-    rig.targets = vec![FlatTarget { dense: prims == 1, ..Default::default() }; m_targets];
-    let mut any_normal = vec![false; m_targets];
-    let mut any_tangent = vec![false; m_targets];
-    for (_, n) in &skinned {
-        for p in &n.mesh.as_ref().unwrap().primitives {
+    for (node, n, skin) in &meshes {
+        let mesh = n.mesh.as_ref().unwrap();
+        let m_targets = mesh.primitives.iter().map(|p| p.targets.len()).max().unwrap_or(0);
+        let all_have_all = mesh.primitives.iter().all(|p| p.targets.len() == m_targets);
+        let first_vertex = (rig.position.len() / 3) as u32;
+        let first_target = rig.targets.len();
+        // every primitive brings its rows: the concatenation is dense
+        rig.targets.extend((0..m_targets).map(|_| FlatTarget { dense: all_have_all, ..Default::default() }));
+        let mut any_normal = vec![false; m_targets];
+        let mut any_tangent = vec![false; m_targets];
+        for p in &mesh.primitives {
             for (m, t) in p.targets.iter().enumerate() {
                 any_normal[m] |= !t.normal.is_empty();
                 any_tangent[m] |= !t.tangent.is_empty();
             }
         }
-    }
-    for (_, n) in &skinned {
-        for p in &n.mesh.as_ref().unwrap().primitives {
+        for p in &mesh.primitives {
             let at = &p.attributes;
             let count = at.position.len();
-            let first = (rig.position.len() / 3) as u32;
-            if at.normal.len() != count || at.tangent.len() != count {
-                return Err(Error::new(sys::SKINRT_E_INVALID, "normal / tangent length differs from position length"));
+            let local_first = (rig.position.len() / 3) as u32 - first_vertex; // target rows count from the section's first vertex
+            if (!at.normal.is_empty() && at.normal.len() != count) || (!at.tangent.is_empty() && at.tangent.len() != count) {
+                return Err(Error::new(sys::SKINRT_E_INVALID, "primitive attribute lengths differ"));
             }
             for v in 0..count {
                 rig.position.extend_from_slice(&at.position[v]);
-                rig.normal.extend_from_slice(&at.normal[v]);
-                rig.tangent.extend_from_slice(&at.tangent[v]);
+                rig.normal.extend_from_slice(&if at.normal.is_empty() { [0.0; 3] } else { at.normal[v] });
+                rig.tangent.extend_from_slice(&if at.tangent.is_empty() { [0.0; 4] } else { at.tangent[v] });
             }
             for k in 0..k_sets {
-                let have = k < at.joints.len() && k < at.weights.len();
+                // an un-skinned section's sets are not read by the library: zeros
+                let have = *skin >= 0 && k < at.joints.len() && k < at.weights.len();
                 if have && (at.joints[k].len() != count || at.weights[k].len() != count) {
                     return Err(Error::new(sys::SKINRT_E_INVALID, "joints / weights length differs from position length"));
                 }
@@ -261,10 +320,10 @@ pub fn flatten(scenes: &[SceneAsset], animations: &[AnimationAsset], scene: Opti
                 {
                     return Err(Error::new(sys::SKINRT_E_INVALID, "morph target length differs from position length"));
                 }
-                let dst = &mut rig.targets[m];
+                let dst = &mut rig.targets[first_target + m];
                 for v in 0..count {
                     if !dst.dense {
-                        dst.indices.push(first + v as u32);
+                        dst.indices.push(local_first + v as u32);
                     }
                     dst.position.extend_from_slice(&src.position[v]);
                     if any_normal[m] {
@@ -285,16 +344,20 @@ pub fn flatten(scenes: &[SceneAsset], animations: &[AnimationAsset], scene: Opti
                 }
             }
         }
-    }
-    // default weights (a13): node.weights if non-empty, else mesh.weights, else zeros
-    if m_targets > 0 {
-        if let Some((_, n0)) = skinned.first() {
-            let src = if !n0.weights.is_empty() { &n0.weights } else { &n0.mesh.as_ref().unwrap().weights };
-            rig.default_weights = vec![0.0; m_targets];
-            for (d, s) in rig.default_weights.iter_mut().zip(src.iter()) {
-                *d = *s;
-            }
+        // default weights (a13): node.weights if non-empty, else mesh.weights, else zeros
+        let src = if !n.weights.is_empty() { &n.weights } else { &mesh.weights };
+        rig.default_weights.resize(rig.targets.len(), 0.0);
+        for (d, s) in rig.default_weights[first_target..].iter_mut().zip(src.iter()) {
+            *d = *s;
         }
+        rig.sections.push(sys::skinrt_section_desc {
+            node: *node,
+            skin: *skin,
+            first_vertex,
+            vertex_count: (rig.position.len() / 3) as u32 - first_vertex,
+            first_target: first_target as u32,
+            target_count: m_targets as u32,
+        });
     }
     Ok(rig)
 }
@@ -306,6 +369,7 @@ pub struct RigDesc<'a> {
     _clips: Vec<sys::skinrt_clip_desc>,
     _channels: Vec<Vec<sys::skinrt_channel_desc>>,
     _targets: Vec<sys::skinrt_morph_target_desc>,
+    _skins: Vec<sys::skinrt_skin_desc>,
     _joint_ptrs: Vec<*const u16>,
     _weight_ptrs: Vec<*const f32>,
 }
@@ -340,7 +404,7 @@ impl<'a> RigDesc<'a> {
             .targets
             .iter()
             .map(|t| sys::skinrt_morph_target_desc {
-                count: if t.dense { vertex_count } else { t.indices.len() as u32 },
+                count: (t.position.len() / 3) as u32, // dense: the section's vertex count
                 indices: if t.dense { std::ptr::null() } else { ptr(&t.indices) },
                 position: ptr(&t.position),
                 normal: ptr(&t.normal),
@@ -349,6 +413,11 @@ impl<'a> RigDesc<'a> {
             .collect();
         let joint_ptrs: Vec<*const u16> = rig.joints.iter().map(|j| ptr(j)).collect();
         let weight_ptrs: Vec<*const f32> = rig.weights.iter().map(|w| ptr(w)).collect();
+        let skins: Vec<sys::skinrt_skin_desc> = rig
+            .skins
+            .iter()
+            .map(|k| sys::skinrt_skin_desc { joint_count: k.joint_node.len() as u32, joint_node: ptr(&k.joint_node), inverse_bind: ptr(&k.inverse_bind) })
+            .collect();
         let desc = sys::skinrt_rig_desc {
             struct_size: std::mem::size_of::<sys::skinrt_rig_desc>() as u32,
             node_count: rig.parent.len() as u32,
@@ -358,9 +427,10 @@ impl<'a> RigDesc<'a> {
             scale: ptr(&rig.scale),
             matrix: ptr(&rig.matrix),
             has_matrix: ptr(&rig.has_matrix),
-            joint_count: rig.joint_node.len() as u32,
-            joint_node: ptr(&rig.joint_node),
-            inverse_bind: ptr(&rig.inverse_bind),
+            // the long form: skins[] and sections[] (joint_count / joint_node / inverse_bind are the one-skin short form)
+            joint_count: 0,
+            joint_node: std::ptr::null(),
+            inverse_bind: std::ptr::null(),
             clip_count: clips.len() as u32,
             clips: ptr(&clips),
             vertex_count,
@@ -374,8 +444,12 @@ impl<'a> RigDesc<'a> {
             target_count: targets.len() as u32,
             targets: ptr(&targets),
             default_weights: ptr(&rig.default_weights),
+            skin_count: skins.len() as u32,
+            skins: ptr(&skins),
+            section_count: rig.sections.len() as u32,
+            sections: ptr(&rig.sections),
         };
         // moving the Vecs into the struct does not move their heap buffers: the pointers above stay valid
-        RigDesc { desc, _rig: rig, _clips: clips, _channels: channels, _targets: targets, _joint_ptrs: joint_ptrs, _weight_ptrs: weight_ptrs }
+        RigDesc { desc, _rig: rig, _clips: clips, _channels: channels, _targets: targets, _skins: skins, _joint_ptrs: joint_ptrs, _weight_ptrs: weight_ptrs }
     }
 }

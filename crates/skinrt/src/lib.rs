@@ -49,6 +49,18 @@ pub struct SkinMatrix {
     pub normal: [[f32; 4]; 3],
 }
 
+/// `InstanceUniform` exactly as the reference uploads it for a mesh node without a skin
+/// (crates/renderer/src/renderer/uniform/transform.rs:8-59; shader.wgsl:143-152): 124 bytes, align 4.
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct InstanceUniform {
+    pub transform: [[f32; 4]; 4],
+    /// Mat3(inverse(transform)^T), each column padded to 16 bytes
+    pub normal: [[f32; 4]; 3],
+    pub _pad: [f32; 3],
+}
+const _: () = assert!(std::mem::size_of::<InstanceUniform>() == sys::SKINRT_INSTANCE_UNIFORM_BYTES);
+
 /// One HIP device + stream.  Drive a context and its crowds from one thread (the reference renders from one thread,
 /// crates/renderer/src/state.rs:236).
 pub struct Context {
@@ -79,7 +91,19 @@ impl Context {
         check(unsafe { sys::skinrt_upload_rig(self.raw, &d.desc, &mut raw) })?;
         let mut info = sys::skinrt_rig_info::default();
         check(unsafe { sys::skinrt_get_rig_info(raw, &mut info) })?;
-        Ok(Rig { raw, info, clip_length: flat.clip_length.clone(), _ctx: PhantomData })
+        let mut skins = Vec::with_capacity(info.skin_count as usize);
+        for k in 0..info.skin_count {
+            let mut l = sys::skinrt_skin_layout::default();
+            check(unsafe { sys::skinrt_rig_skin_layout(raw, k, &mut l) })?;
+            skins.push(l);
+        }
+        let mut sections = Vec::with_capacity(info.section_count as usize);
+        for k in 0..info.section_count {
+            let mut l = sys::skinrt_section_layout::default();
+            check(unsafe { sys::skinrt_rig_section_layout(raw, k, &mut l) })?;
+            sections.push(l);
+        }
+        Ok(Rig { raw, info, clip_length: flat.clip_length.clone(), skins, sections, _ctx: PhantomData })
     }
 }
 
@@ -93,6 +117,10 @@ pub struct Rig<'c> {
     raw: *mut sys::skinrt_rig,
     pub info: sys::skinrt_rig_info,
     pub clip_length: Vec<f32>,
+    /// where each skin's joints lie in the palette (`FlatRig::skins` order)
+    pub skins: Vec<sys::skinrt_skin_layout>,
+    /// each mesh node's vertex range, target range, skin (or -1) and — un-skinned — its pseudo-joint (`FlatRig::sections` order)
+    pub sections: Vec<sys::skinrt_section_layout>,
     _ctx: PhantomData<&'c Context>,
 }
 
@@ -130,6 +158,23 @@ impl Crowd<'_> {
         }
         check(unsafe { sys::skinrt_set_clocks(self.raw, tau.as_ptr(), clip_id.map(|c| c.as_ptr()).unwrap_or(ptr::null())) })
     }
+    /// The same from DEVICE memory, stream-ordered: nothing is validated on the host and nothing waits (a clip id that is
+    /// out of range means "at rest").  For frame loops that keep their clocks on the GPU.
+    ///
+    /// # Safety
+    /// `dev_tau` (`instances` f32) and `dev_clip_id` (`instances` u32, or null = unchanged) must be valid device pointers
+    /// that stay untouched until the stream has passed the copy.
+    pub unsafe fn set_clocks_async(&mut self, dev_tau: *const f32, dev_clip_id: *const u32) -> Result<(), Error> {
+        check(sys::skinrt_set_clocks_async(self.raw, dev_tau, dev_clip_id))
+    }
+    /// `tau = fmodf(tau + dt * rate, clip_length)` on the device, per instance (`dev_rate` null = 1); instances at rest
+    /// keep their clock.  Enqueued like `evaluate`: a frame is `advance_clocks(dt)` + `evaluate(STAGE_ALL)`, no host wait.
+    ///
+    /// # Safety
+    /// `dev_rate` is null or a device pointer to `instances` f32.
+    pub unsafe fn advance_clocks(&mut self, dt: f32, dev_rate: *const f32) -> Result<(), Error> {
+        check(sys::skinrt_advance_clocks(self.raw, dt, dev_rate))
+    }
     /// `weights[instance][target]`; `None` restores the rig's defaults (NodeAsset.weights / MeshAsset.weights).
     pub fn set_morph_weights(&mut self, weights: Option<&[f32]>) -> Result<(), Error> {
         if let Some(w) = weights {
@@ -161,6 +206,19 @@ impl Crowd<'_> {
         check(unsafe { sys::skinrt_export_skin_uniform(self.raw, instance, out.as_mut_ptr().cast()) })?;
         Ok(out)
     }
+    /// The same for skin `skin` of a rig with several (`Rig::skins`): that skin's joints from slot 0, zeros behind them.
+    pub fn skin_uniform_of(&self, skin: u32, instance: u32) -> Result<Box<[SkinMatrix; 128]>, Error> {
+        let mut out = Box::new([SkinMatrix { transform: [[0.0; 4]; 4], normal: [[0.0; 4]; 3] }; 128]);
+        check(unsafe { sys::skinrt_export_skin_uniform_of(self.raw, skin, instance, out.as_mut_ptr().cast()) })?;
+        Ok(out)
+    }
+    /// `InstanceUniform` of node `node` (an index into `FlatRig::node_id`) for one instance: what
+    /// `InstanceUniformBuffer::update` (uniform/transform.rs:40-59) would build from the node's world matrix.
+    pub fn instance_uniform(&self, instance: u32, node: u32) -> Result<InstanceUniform, Error> {
+        let mut out = InstanceUniform { transform: [[0.0; 4]; 4], normal: [[0.0; 4]; 3], _pad: [0.0; 3] };
+        check(unsafe { sys::skinrt_export_instance_uniform(self.raw, instance, node, (&mut out as *mut InstanceUniform).cast()) })?;
+        Ok(out)
+    }
     /// Device pointers to the skinned positions / normals / tangents (`[instance][vertex][3]` f32 each), for a
     /// storage-buffer vertex pull or an interop import; valid until the crowd is dropped.
     pub fn device_outputs(&self) -> Result<[*mut f32; 3], Error> {
@@ -187,6 +245,15 @@ impl Crowd<'_> {
     /// `dev_dst` and `dev_tex_coords` (`[vertex][2]` f32, or null = zeros) must be valid device pointers of those sizes.
     pub unsafe fn texture_skin_vertices_device(&self, first: u32, count: u32, dev_tex_coords: *const f32, dev_dst: *mut u8) -> Result<(), Error> {
         check(sys::skinrt_export_interleaved_device(self.raw, first, count, sys::SKINRT_LAYOUT_TEXTURE_SKIN, dev_tex_coords, dev_dst.cast()))
+    }
+    /// The same for one mesh node (`Rig::sections[section]`): `count * section.vertex_count * 68` bytes; joint indices are
+    /// local to the section's skin, as the loader gave them.
+    ///
+    /// # Safety
+    /// As `texture_skin_vertices_device`; `dev_tex_coords` holds the SECTION's vertices.
+    pub unsafe fn texture_skin_vertices_section_device(&self, section: u32, first: u32, count: u32, dev_tex_coords: *const f32,
+                                                       dev_dst: *mut u8) -> Result<(), Error> {
+        check(sys::skinrt_export_interleaved_section_device(self.raw, section, first, count, sys::SKINRT_LAYOUT_TEXTURE_SKIN, dev_tex_coords, dev_dst.cast()))
     }
     pub fn instances(&self) -> u32 { self.instances }
     pub fn joints(&self) -> u32 { self.joints }
