@@ -1,14 +1,15 @@
 """Flat rig files: a RigData as one `.npz` of plain arrays (no pickles), used for the golden
 fixtures and for handing rigs between tools.  The arrays are exactly the fields of
 skinrt_rig_desc (include/skinrt.h); ragged parts (channels, morph targets) are stored as
-concatenated pools plus offset tables."""
+concatenated pools plus offset tables.  Rigs in the long form (several skins / mesh sections, ABI 6) add `skins`,
+`skin_joint_node`, `skin_inverse_bind` and `sections`; rigs in the short form are stored exactly as before."""
 from __future__ import annotations
 
 from typing import Dict
 
 import numpy as np
 
-from .abi import Channel, MorphTarget, RigData
+from .abi import Channel, MorphTarget, RigData, Section, Skin
 
 _VALUE_WIDTH = {0: 3, 1: 4, 2: 3}  # translation, rotation, scale; weights (path 3): the rig's target count
 
@@ -22,6 +23,14 @@ def rig_to_arrays(rig: RigData, prefix: str = "rig_") -> Dict[str, np.ndarray]:
     a["joint_node"] = rig.joint_node
     if rig.inverse_bind is not None:
         a["inverse_bind"] = rig.inverse_bind
+    if rig.skins is not None:  # one row per skin {joint_count, has_inverse_bind}; pools in skin order
+        a["skins"] = np.array([(sk.joint_node.shape[0], sk.inverse_bind is not None) for sk in rig.skins], np.uint32).reshape(-1, 2)
+        a["skin_joint_node"] = np.concatenate([sk.joint_node for sk in rig.skins] + [np.zeros(0, np.uint32)])
+        a["skin_inverse_bind"] = np.concatenate([sk.inverse_bind.reshape(-1, 16) for sk in rig.skins if sk.inverse_bind is not None]
+                                                + [np.zeros((0, 16), np.float32)])
+    if rig.sections is not None:  # {node, skin (-1 = none), first_vertex, vertex_count, first_target, target_count}
+        a["sections"] = np.array([(sc.node, sc.skin, sc.first_vertex, sc.vertex_count, sc.first_target, sc.target_count)
+                                  for sc in rig.sections], np.int64).reshape(-1, 6)
     a["position"], a["normal"], a["tangent"] = rig.position, rig.normal, rig.tangent
     a["joints"] = np.stack(rig.joints) if rig.joints else np.zeros((0, rig.vertex_count, 4), np.uint16)
     a["weights"] = np.stack(rig.weights) if rig.weights else np.zeros((0, rig.vertex_count, 4), np.float32)
@@ -39,7 +48,7 @@ def rig_to_arrays(rig: RigData, prefix: str = "rig_") -> Dict[str, np.ndarray]:
     # morph targets: one row per target {count, compacted, has_normal, has_tangent}
     trow, tidx, tpos, tnrm, ttan = [], [], [], [], []
     for t in rig.targets:
-        cnt = rig.vertex_count if t.indices is None else int(t.indices.shape[0])
+        cnt = int(t.position.shape[0]) if t.indices is None else int(t.indices.shape[0])  # dense: the section's vertex count
         trow.append((cnt, t.indices is not None, t.normal is not None, t.tangent is not None))
         if t.indices is not None: tidx.append(t.indices)
         tpos.append(t.position.reshape(cnt, 3))
@@ -61,8 +70,24 @@ def rig_from_arrays(z, prefix: str = "rig_") -> RigData:
     to = vo = 0
     times, values = g("channel_times"), g("channel_values")
     n_targets = int(g("targets").shape[0])
+    skins = sections = None
+    if g("skins") is not None:
+        skins, jo, bo = [], 0, 0
+        for jc, has_ibm in g("skins").tolist():
+            ibm = None
+            if has_ibm:
+                ibm = g("skin_inverse_bind")[bo:bo + jc].copy(); bo += jc
+            skins.append(Skin(g("skin_joint_node")[jo:jo + jc].copy(), ibm)); jo += jc
+    if g("sections") is not None:
+        sections = [Section(*(int(x) for x in row)) for row in g("sections").tolist()]
+
+    def weights_width(node):  # a weights channel carries the targets of the section on its node
+        if sections is None:
+            return n_targets
+        return next((sc.target_count for sc in sections if sc.node == node and sc.target_count), 0)
+
     for ci, node, path, interp, kc in g("channels").tolist():
-        w = (n_targets if path == 3 else _VALUE_WIDTH[path]) * (3 if interp == 2 else 1)
+        w = (weights_width(node) if path == 3 else _VALUE_WIDTH[path]) * (3 if interp == 2 else 1)
         clips[ci].append(Channel(node, path, interp, times[to:to + kc].copy(), values[vo:vo + kc * w].reshape(kc, -1).copy()))
         to += kc; vo += kc * w
     targets = []
@@ -83,7 +108,7 @@ def rig_from_arrays(z, prefix: str = "rig_") -> RigData:
                    joint_node=g("joint_node"), inverse_bind=g("inverse_bind"), matrix=g("matrix"),
                    has_matrix=g("has_matrix"), position=g("position"), normal=g("normal"), tangent=g("tangent"),
                    joints=[joints[k] for k in range(joints.shape[0])], weights=[weights[k] for k in range(weights.shape[0])],
-                   clips=clips, targets=targets, default_weights=g("default_weights"))
+                   clips=clips, targets=targets, default_weights=g("default_weights"), skins=skins, sections=sections)
 
 
 def save_rig(path: str, rig: RigData, **extra: np.ndarray) -> None:

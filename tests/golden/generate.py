@@ -15,7 +15,7 @@ Each fixture is one .npz (plain arrays, no pickles):
   cfg            [cubic_quirk, normalize_outputs]
   key_index      u32  [I][Cmax]   (bit-exact)
   world          f32  [I][N][12]  rows, skinrt_get_world layout
-  palette        f32  [I][J][24]  skinrt_get_palette layout
+  palette        f32  [I][P][24]  skinrt_get_palette layout (P = all skins' joints + one entry per un-skinned mesh node)
   position / normal / tangent  f32 [I][V][3];  aabb f32 [I][2][3]
 """
 import os
@@ -31,8 +31,13 @@ from renderer_amd import rigfile, synth  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-# name -> (spec, instances, cubic_quirk, normalize_outputs, with_root)
+# name -> (spec, instances, cubic_quirk, normalize_outputs, with_root[, multi-skin arguments of synth.make_multi_rig])
 FIXTURES = {
+    # ABI 6: three skins on one node tree + two rigid props (un-skinned sections on two nodes), targets and a weights
+    # channel split over the sections; the world rows a caller's InstanceUniform export is made from are in `world`
+    "tiny_three_skins_two_props": (synth.tiny_spec(seed=107, verts=160, joints=9, nodes=14, clips=2, keys=4, targets=5, sets=2,
+                                                   weight_channels=1), 6, 1, 0, True,
+                                   dict(seed=7, fractions=(0.4, 0.35, 0.25), rigid_frac=0.1, rigid_sections=2)),
     # small: <= 64 verts, <= 8 joints, <= 3 keys
     "tiny_all_features": (synth.tiny_spec(seed=101, matrix_nodes=2), 5, 1, 0, True),
     "tiny_spec_hermite": (synth.tiny_spec(seed=102, frac_cubic=0.6), 4, 0, 0, False),
@@ -50,8 +55,10 @@ FIXTURES = {
 
 
 def make(name):
-    spec, inst, quirk, norm, with_root = FIXTURES[name]
+    spec, inst, quirk, norm, with_root = FIXTURES[name][:5]
     rig = synth.make_rig(spec)
+    if len(FIXTURES[name]) > 5:
+        rig, _ = synth.make_multi_rig(rig, **FIXTURES[name][5])
     crowd = synth.make_crowd(spec, rig, instances=inst, with_root=with_root)
     res = Oracle("f32").evaluate(rig, crowd.tau, crowd.clip_id, crowd.morph_weights, crowd.root,
                                  cubic_quirk=quirk, normalize_outputs=norm)
