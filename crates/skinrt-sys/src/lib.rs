@@ -274,6 +274,7 @@ extern "C" {
     pub fn skinrt_export_skin_uniform_of_device(crowd: *mut skinrt_crowd, skin: u32, first: u32, count: u32, dev_dst: *mut c_void) -> c_int;
     pub fn skinrt_export_interleaved_section_device(crowd: *mut skinrt_crowd, section: u32, first: u32, count: u32, layout: u32,
                                                     dev_attr: *const f32, dev_dst: *mut c_void) -> c_int;
+    pub fn skinrt_export_skin_storage_device(crowd: *mut skinrt_crowd, skin: u32, first: u32, count: u32, slots: u32, dev_dst: *mut c_void) -> c_int;
     pub fn skinrt_export_instance_uniform_device(crowd: *mut skinrt_crowd, first: u32, count: u32, dev_nodes: *const u32, node_count: u32,
                                                  stride: u32, dev_dst: *mut c_void) -> c_int;
     pub fn skinrt_export_skin_uniform_device(crowd: *mut skinrt_crowd, first: u32, count: u32, dev_dst: *mut c_void) -> c_int;

@@ -452,6 +452,14 @@ SKINRT_API int skinrt_export_interleaved_device(skinrt_crowd* crowd, uint32_t fi
 SKINRT_API int skinrt_export_skin_uniform_of_device(skinrt_crowd* crowd, uint32_t skin, uint32_t first, uint32_t count, void* dev_dst);
 SKINRT_API int skinrt_export_interleaved_section_device(skinrt_crowd* crowd, uint32_t section, uint32_t first, uint32_t count,
                                                         uint32_t layout, const float* dev_attr, void* dev_dst);
+/* The palette of skin `skin` for a STORAGE-buffer binding: `slots` SkinMatrix records (112 B) per instance instead of
+ * the uniform array's 128, slots >= the skin's joint count (SKINRT_E_LIMIT otherwise), records >= the joint count
+ * zero; dev_dst receives count * slots * 112 bytes.  With slots = 128 the bytes are those of
+ * skinrt_export_skin_uniform_of_device.  This is what lifts MAX_JOINTS = 128 (uniform/skin.rs:10, shader.wgsl:70:
+ * `array<JointItem, 128>` in a uniform binding) once the render core declares the binding
+ * `var<storage, read> joints: array<JointItem>` (renderer/mod.rs:236-248 -> BufferBindingType::Storage). */
+SKINRT_API int skinrt_export_skin_storage_device(skinrt_crowd* crowd, uint32_t skin, uint32_t first, uint32_t count, uint32_t slots,
+                                                 void* dev_dst);
 /* InstanceUniform records for instances [first, first + count) x the listed nodes, one kernel:
  * record (k, n) at dev_dst + (k * node_count + n) * stride, stride >= 124 and a multiple of 4 (256 suits wgpu's
  * dynamic uniform offsets); bytes 124..stride of a record are not written.  dev_nodes: DEVICE array

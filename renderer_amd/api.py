@@ -38,6 +38,7 @@ EXPORTS = [
     "skinrt_set_clocks_async", "skinrt_advance_clocks", "skinrt_get_clocks",
     "skinrt_export_skin_uniform_of", "skinrt_export_interleaved_section", "skinrt_export_instance_uniform",
     "skinrt_export_skin_uniform_of_device", "skinrt_export_interleaved_section_device", "skinrt_export_instance_uniform_device",
+    "skinrt_export_skin_storage_device",
     "skinrt_node_create", "skinrt_node_destroy", "skinrt_node_shard_count", "skinrt_node_get_shard", "skinrt_node_set_clocks",
     "skinrt_node_set_morph_weights", "skinrt_node_set_root_transforms", "skinrt_node_evaluate", "skinrt_node_synchronize",
     "skinrt_node_download_aabbs",
@@ -98,6 +99,7 @@ def load_library() -> C.CDLL:
         "skinrt_export_interleaved_section": [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp],
         "skinrt_export_instance_uniform": [vp, C.c_uint32, C.c_uint32, vp],
         "skinrt_export_skin_uniform_of_device": [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp],
+        "skinrt_export_skin_storage_device": [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp],
         "skinrt_export_interleaved_section_device": [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp],
         "skinrt_export_instance_uniform_device": [vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp],
         "skinrt_shard_range": [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
@@ -412,6 +414,10 @@ class Crowd:
 
     def skin_uniform_of_device(self, skin: int, first: int, count: int, dev_dst: int):
         _check(self.ctx.lib.skinrt_export_skin_uniform_of_device(self.handle, skin, first, count, C.c_void_p(dev_dst)))
+
+    def skin_storage_device(self, skin: int, first: int, count: int, slots: int, dev_dst: int):
+        """`slots` SkinMatrix records per instance (storage-buffer palette: no 128-joint limit)."""
+        _check(self.ctx.lib.skinrt_export_skin_storage_device(self.handle, skin, first, count, slots, C.c_void_p(dev_dst)))
 
     def interleaved_section_device(self, section: int, first: int, count: int, layout: int, dev_attr: int, dev_dst: int):
         _check(self.ctx.lib.skinrt_export_interleaved_section_device(self.handle, section, first, count, layout,

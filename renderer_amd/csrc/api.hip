@@ -674,7 +674,7 @@ int skinrt_download(skinrt_ctx* ctx, const void* dev_src, void* host_dst, uint64
 namespace {
 
 // the skin's span of the palette, or a failure code; a rig without skins has nothing to export
-int skin_span(skinrt_crowd* c, uint32_t skin, SkinSpan* out) {
+int skin_span(skinrt_crowd* c, uint32_t skin, SkinSpan* out, uint32_t slots = SKINRT_MAX_JOINTS_REFERENCE) {
     const CompiledRig& h = c->rig->host;
     if (skin >= h.skins.size()) {
         if (skin == 0) { *out = SkinSpan{0, 0}; return SKINRT_OK; }  // no skin at all: an all-zero palette, as J = 0 always gave
@@ -682,7 +682,8 @@ int skin_span(skinrt_crowd* c, uint32_t skin, SkinSpan* out) {
     }
     *out = h.skins[skin];
     // assert!(items.len() <= MAX_JOINTS) — renderer/src/renderer/uniform/skin.rs:40,60
-    if (out->count > SKINRT_MAX_JOINTS_REFERENCE) return fail(SKINRT_E_LIMIT, "the reference palette holds at most 128 joints");
+    if (slots == SKINRT_MAX_JOINTS_REFERENCE && out->count > slots) return fail(SKINRT_E_LIMIT, "the reference palette holds at most 128 joints");
+    if (out->count > slots) return fail(SKINRT_E_LIMIT, "fewer slots per instance than the skin has joints");
     return SKINRT_OK;
 }
 
@@ -753,16 +754,17 @@ int export_interleaved_host(skinrt_crowd* c, int64_t section, uint32_t instance,
     return SKINRT_OK;
 }
 
-int export_skin_uniform_dev(skinrt_crowd* c, uint32_t skin, uint32_t first, uint32_t count, void* dev_dst) {
+int export_skin_uniform_dev(skinrt_crowd* c, uint32_t skin, uint32_t first, uint32_t count, void* dev_dst, uint32_t slots = SKINRT_MAX_JOINTS_REFERENCE) {
     if (int rc = check_crowd(c)) return rc;
     if (count == 0) return SKINRT_OK;
     if (!dev_dst) return fail(SKINRT_E_INVALID, "dev_dst is NULL");
     if (reinterpret_cast<uintptr_t>(dev_dst) & 15u) return fail(SKINRT_E_INVALID, "dev_dst must be 16-byte aligned");
     if ((uint64_t)first + count > c->I) return fail(SKINRT_E_RANGE, "instance range out of range");
     SkinSpan sp;
-    if (int rc = skin_span(c, skin, &sp)) return rc;
+    if (int rc = skin_span(c, skin, &sp, slots)) return rc;
+    if (slots == 0) return SKINRT_OK;
     HIP_TRY(hipSetDevice(c->ctx->cfg.device));
-    HIP_TRY(launch_export_skin_uniform(c->dev(), c->rig->host.J, sp.first, sp.count, first, count, dev_dst, c->ctx->stream));
+    HIP_TRY(launch_export_skin_uniform(c->dev(), c->rig->host.J, sp.first, sp.count, slots, first, count, dev_dst, c->ctx->stream));
     return SKINRT_OK;
 }
 
@@ -796,6 +798,9 @@ int skinrt_export_skin_uniform_device(skinrt_crowd* c, uint32_t first, uint32_t 
 }
 int skinrt_export_skin_uniform_of_device(skinrt_crowd* c, uint32_t skin, uint32_t first, uint32_t count, void* dev_dst) {
     return export_skin_uniform_dev(c, skin, first, count, dev_dst);
+}
+int skinrt_export_skin_storage_device(skinrt_crowd* c, uint32_t skin, uint32_t first, uint32_t count, uint32_t slots, void* dev_dst) {
+    return export_skin_uniform_dev(c, skin, first, count, dev_dst, slots);
 }
 int skinrt_export_interleaved_device(skinrt_crowd* c, uint32_t first, uint32_t count, uint32_t layout, const float* dev_attr, void* dev_dst) {
     return export_interleaved_dev(c, -1, first, count, layout, dev_attr, dev_dst);

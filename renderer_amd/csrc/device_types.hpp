@@ -127,9 +127,10 @@ uint32_t skin_build_flags();  // SKINRT_BUILD_* bits of the skin kernels' transl
 hipError_t launch_export_interleaved(const CrowdDev& cr, uint32_t V, uint32_t v_first, uint32_t v_count, const uint32_t* joints0,
                                      const float* weights0, const float* attr, uint32_t layout, uint32_t first, uint32_t count, void* dst,
                                      hipStream_t s);
-// palette entries [j_first, j_first + j_count) of every instance's P entries (one skin's joints), j_count <= 128
-hipError_t launch_export_skin_uniform(const CrowdDev& cr, uint32_t P, uint32_t j_first, uint32_t j_count, uint32_t first, uint32_t count,
-                                      void* dst, hipStream_t s);
+// palette entries [j_first, j_first + j_count) of every instance's P entries (one skin's joints) as `slots` >= j_count
+// SkinMatrix records per instance (128: the reference's uniform array)
+hipError_t launch_export_skin_uniform(const CrowdDev& cr, uint32_t P, uint32_t j_first, uint32_t j_count, uint32_t slots, uint32_t first,
+                                      uint32_t count, void* dst, hipStream_t s);
 // kernels_geom.hip: calculate_tangent on the device (load time)
 size_t tangent_work_bytes(uint32_t vertices, uint32_t corners);
 hipError_t tangent_static_setup(int device);                             // once per device, that device current

@@ -96,12 +96,13 @@ __global__ __launch_bounds__(256) void k_export_interleaved(const ExportSrc src,
 }
 
 // One thread per (instance, palette slot): 24 floats in (joint rows, packed normal rows, padding), 28 floats out.
-// The skin's joints are entries [j_first, j_first + J) of every instance's P palette entries.
-__global__ __launch_bounds__(256) void k_export_skin_uniform(const float* palette, uint32_t P, uint32_t j_first, uint32_t J, uint32_t first,
-                                                             uint32_t count, float4* dst) {
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= count * 128u) return;
-    const uint32_t k = g >> 7, j = g & 127u;
+// The skin's joints are entries [j_first, j_first + J) of every instance's P palette entries; an instance's record has
+// `slots` SkinMatrix entries (128 = the reference's uniform array; any count >= J for a storage buffer), those >= J zero.
+__global__ __launch_bounds__(256) void k_export_skin_uniform(const float* palette, uint32_t P, uint32_t j_first, uint32_t J, uint32_t slots,
+                                                             uint32_t first, uint32_t count, float4* dst) {
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (uint64_t)count * slots) return;
+    const uint32_t k = (uint32_t)(g / slots), j = (uint32_t)(g - (uint64_t)k * slots);
     float4* o = dst + (size_t)g * 7;
     if (j >= J) {
         const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -141,14 +142,15 @@ hipError_t launch_export_interleaved(const CrowdDev& cr, uint32_t Vall, uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_export_skin_uniform(const CrowdDev& cr, uint32_t P, uint32_t j_first, uint32_t J, uint32_t first, uint32_t count, void* dst,
-                                      hipStream_t s) {
-    if (count == 0) return hipSuccess;
-    if ((uint64_t)first + count > cr.I || J > 128 || (uint64_t)j_first + J > P || (reinterpret_cast<uintptr_t>(dst) & 15u) ||
-        (uint64_t)count * 128 > 0x7fffffffull)
+hipError_t launch_export_skin_uniform(const CrowdDev& cr, uint32_t P, uint32_t j_first, uint32_t J, uint32_t slots, uint32_t first, uint32_t count,
+                                      void* dst, hipStream_t s) {
+    if (count == 0 || slots == 0) return hipSuccess;
+    const uint64_t threads = (uint64_t)count * slots;
+    if ((uint64_t)first + count > cr.I || J > slots || (uint64_t)j_first + J > P || (reinterpret_cast<uintptr_t>(dst) & 15u) ||
+        (threads + 255) / 256 > 0x7fffffffull)
         return hipErrorInvalidValue;
-    const uint32_t threads = count * 128u;
-    hipLaunchKernelGGL(k_export_skin_uniform, dim3((threads + 255) / 256), dim3(256), 0, s, cr.palette, P, j_first, J, first, count, static_cast<float4*>(dst));
+    hipLaunchKernelGGL(k_export_skin_uniform, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, cr.palette, P, j_first, J, slots, first, count,
+                       static_cast<float4*>(dst));
     return hipGetLastError();
 }
 

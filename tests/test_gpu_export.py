@@ -143,3 +143,49 @@ def test_device_export_c3_shape_rate():
     finally:
         dev.close()
         c.close(); r.close(); ctx.close()
+
+
+def test_storage_buffer_palette_lifts_the_128_joint_limit(oracle32):
+    """skinrt_export_skin_storage_device ("lifts MAX_JOINTS=128 by switching the palette binding to a
+    storage buffer"): a 300-joint chain rig — refused by the uniform-array exports, as the reference's assert!
+    (uniform/skin.rs:40,60) refuses it — exported as `slots` SkinMatrix records per instance; entries equal the oracle's
+    SkinMatrix palette bit for bit, the tail is zero, too few slots is SKINRT_E_LIMIT, and with slots = 128 a small rig
+    gives the uniform array's bytes."""
+    spec = synth.scaled(synth.CONFIGS["c5"], nodes=300, joints=300, verts=512, targets=0, keys=4)
+    I = 4
+    rig, crowd, ctx, r, c = _crowd(spec, I, exact_arithmetic=1)
+    ref = oracle32.evaluate(rig, crowd.tau, crowd.clip_id, crowd.morph_weights, want=("palette",))
+    J = rig.joint_count
+    assert J == 300
+    dev = DeviceBuffers()
+    try:
+        with pytest.raises(api.SkinrtError) as e:
+            c.skin_uniform_device(0, 1, dev.empty(128 * 112))
+        assert e.value.code == abi.E_LIMIT
+        for slots in (J, 320):
+            dst = dev.empty(3 * slots * 112 + 64)
+            c.skin_storage_device(0, 1, 3, slots, dst)
+            ctx.synchronize()
+            raw = dev.download(dst, (3 * slots * 112 + 64,), np.uint8)
+            assert (raw[3 * slots * 112:] == 0xAB).all(), "wrote past the end of the destination"
+            su = raw[:3 * slots * 112].copy().view(np.float32).reshape(3, slots, 28)
+            assert_equal(su[:, :J].view(np.uint32), np.ascontiguousarray(ref.palette[1:4]).view(np.uint32), f"{slots} slots: SkinMatrix entries")
+            assert (su[:, J:] == 0).all()
+        with pytest.raises(api.SkinrtError) as e:
+            c.skin_storage_device(0, 0, 1, J - 1, dst)
+        assert e.value.code == abi.E_LIMIT
+    finally:
+        dev.close()
+        c.close(); r.close(); ctx.close()
+    # a small rig: 128 slots = the uniform array
+    rig, crowd, ctx, r, c = _crowd(synth.tiny_spec(seed=2), 3)
+    dev = DeviceBuffers()
+    try:
+        a, b = dev.empty(3 * 128 * 112), dev.empty(3 * 128 * 112)
+        c.skin_uniform_device(0, 3, a)
+        c.skin_storage_device(0, 0, 3, 128, b)
+        ctx.synchronize()
+        assert np.array_equal(dev.download(a, (3 * 128 * 112,), np.uint8), dev.download(b, (3 * 128 * 112,), np.uint8))
+    finally:
+        dev.close()
+        c.close(); r.close(); ctx.close()
