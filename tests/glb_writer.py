@@ -2,6 +2,8 @@
 indices in an arbitrary (shuffled) order, hierarchy through `children`, one skin, one skinned
 mesh primitive with morph targets, one animation per clip — so that the native loader + flattener
 (renderer_amd/host) have to rebuild the flat rig: DFS order, joint -> node mapping, channels.
+`write_glb_multi` does the same for a rig with several skins and mesh nodes (RigData.skins / .sections): one glTF
+skin per skin, one mesh per section on the section's node, un-skinned sections without JOINTS / WEIGHTS / skin.
 Written from the glTF 2.0 specification; it is not a general exporter."""
 import json
 import struct
@@ -134,6 +136,93 @@ def write_glb(rig, seed=0, joints_u8=False, weights_u16=False, interleave=True, 
         anims.append({"samplers": samplers, "channels": channels})
     if anims: doc["animations"] = anims
 
+    doc["bufferViews"] = b.views
+    doc["accessors"] = b.accessors
+    while len(b.data) % 4: b.data.append(0)
+    doc["buffers"] = [{"byteLength": len(b.data)}]
+    js = json.dumps(doc, separators=(",", ":")).encode("utf-8")
+    js += b" " * (-len(js) % 4)
+    total = 12 + 8 + len(js) + 8 + len(b.data)
+    return (struct.pack("<III", 0x46546C67, 2, total) + struct.pack("<II", len(js), 0x4E4F534A) + js +
+            struct.pack("<II", len(b.data), 0x004E4942) + bytes(b.data)), perm
+
+
+def write_glb_multi(rig, seed=0):
+    """A rig in the long form (skins + sections) as .glb.  Returns (glb bytes, perm) as write_glb does."""
+    rng = np.random.default_rng(seed)
+    n = rig.node_count
+    perm = rng.permutation(n)
+    b = _Bin()
+    nodes = [None] * n
+    children = [[] for _ in range(n)]
+    roots = []
+    for k in range(n):
+        p = int(rig.parent[k])
+        (roots if p < 0 else children[p]).append(int(perm[k]))
+    for k in range(n):
+        node = {"name": f"n{k}"}
+        if rig.has_matrix is not None and rig.has_matrix[k]:
+            node["matrix"] = _f(rig.matrix[k])
+        else:
+            node["translation"] = _f(rig.translation[k]); node["rotation"] = _f(rig.rotation[k]); node["scale"] = _f(rig.scale[k])
+        if children[k]: node["children"] = children[k]
+        nodes[int(perm[k])] = node
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": roots}], "nodes": nodes}
+    doc["skins"] = []
+    for sk in rig.skin_list():
+        skin = {"joints": [int(perm[j]) for j in sk.joint_node]}
+        if sk.inverse_bind is not None:
+            skin["inverseBindMatrices"] = b.add(sk.inverse_bind.reshape(-1, 16), F32, "MAT4")
+        doc["skins"].append(skin)
+    tan4 = rig.tangent if rig.tangent.shape[1] == 4 else np.concatenate([rig.tangent, np.ones((rig.vertex_count, 1), np.float32)], axis=1)
+    doc["meshes"] = []
+    for sc in rig.section_list():
+        lo, hi = sc.first_vertex, sc.first_vertex + sc.vertex_count
+        v = sc.vertex_count
+        attrs = {}
+        attrs["POSITION"], attrs["NORMAL"] = b.add_interleaved(rig.position[lo:hi], rig.normal[lo:hi])
+        attrs["TANGENT"] = b.add(tan4[lo:hi].astype(np.float32), F32, "VEC4")
+        if sc.skin >= 0:
+            for k in range(rig.set_count):
+                attrs[f"JOINTS_{k}"] = b.add(rig.joints[k][lo:hi].astype(np.uint16), U16, "VEC4")
+                attrs[f"WEIGHTS_{k}"] = b.add(rig.weights[k][lo:hi], F32, "VEC4")
+        prim = {"attributes": attrs, "mode": 4}
+        targets = []
+        for t in rig.targets[sc.first_target:sc.first_target + sc.target_count]:
+            def dense(a, w):
+                if a is None: return None
+                if t.indices is None: return np.asarray(a, np.float32).reshape(v, -1)[:, :w]
+                d = np.zeros((v, w), np.float32); d[t.indices] = np.asarray(a, np.float32).reshape(len(t.indices), -1)[:, :w]
+                return d
+            tj = {"POSITION": b.add(dense(t.position, 3), F32, "VEC3")}
+            dn = dense(t.normal, 3)
+            if dn is not None: tj["NORMAL"] = b.add(dn, F32, "VEC3")
+            dt4 = np.zeros((v, 4), np.float32)
+            dt = dense(t.tangent, 3)
+            if dt is not None: dt4[:, :3] = dt
+            tj["TANGENT"] = b.add(dt4, F32, "VEC4")
+            targets.append(tj)
+        if targets: prim["targets"] = targets
+        mesh = {"primitives": [prim]}
+        if rig.default_weights is not None and sc.target_count:
+            mesh["weights"] = _f(rig.default_weights[sc.first_target:sc.first_target + sc.target_count])
+        doc["meshes"].append(mesh)
+        nodes[int(perm[sc.node])]["mesh"] = len(doc["meshes"]) - 1
+        if sc.skin >= 0: nodes[int(perm[sc.node])]["skin"] = int(sc.skin)
+    anims = []
+    for clip in rig.clips:
+        samplers, channels = [], []
+        for ch in clip:
+            interp = ["LINEAR", "STEP", "CUBICSPLINE"][ch.interpolation]
+            if ch.path == 3:
+                out, gtype, path = np.asarray(ch.values, np.float32).reshape(-1), "SCALAR", "weights"
+            else:
+                w = 4 if ch.path == 1 else 3
+                out, gtype, path = np.asarray(ch.values, np.float32).reshape(-1, w), ("VEC4" if w == 4 else "VEC3"), ["translation", "rotation", "scale"][ch.path]
+            samplers.append({"input": b.add(np.asarray(ch.times, np.float32), F32, "SCALAR"), "output": b.add(out, F32, gtype), "interpolation": interp})
+            channels.append({"sampler": len(samplers) - 1, "target": {"node": int(perm[ch.target_node]), "path": path}})
+        anims.append({"samplers": samplers, "channels": channels})
+    if anims: doc["animations"] = anims
     doc["bufferViews"] = b.views
     doc["accessors"] = b.accessors
     while len(b.data) % 4: b.data.append(0)

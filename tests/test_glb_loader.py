@@ -331,3 +331,81 @@ def test_loaded_glb_evaluates_on_the_gpu(oracle32):
     helpers.assert_equal(got["key_index"], ref["key_index"], "key_index")
     for k in ("world", "palette", "position", "normal", "tangent", "aabb"):
         helpers.assert_equal(got[k].view(np.uint32), np.asarray(ref[k]).view(np.uint32), k)
+
+
+# ---- several skins and mesh nodes in one file (ABI 6) ----------------------------------------------------------------
+def _multi_case(seed=61):
+    from tests.glb_writer import write_glb_multi
+    spec = synth.tiny_spec(seed=seed, verts=300, joints=10, nodes=18, clips=2, keys=4, targets=5, sets=2, weight_channels=1)
+    base = synth.make_rig(spec)
+    rig, tmap = synth.make_multi_rig(base, seed=3, fractions=(0.4, 0.35, 0.25), rigid_frac=0.1, rigid_sections=2)
+    glb, perm = write_glb_multi(rig, seed=5)
+    loaded, order, _ = hostlib.load_glb(glb)
+    crowd = synth.make_crowd(spec, base, instances=4)
+    mw = crowd.morph_weights[:, tmap]
+    return rig, loaded, order, perm, crowd, mw
+
+
+def _sections_by_node(rig):
+    return {sc.node: sc for sc in rig.section_list()}
+
+
+def _weights_for(loaded, rig, mw):
+    """the original rig's [I][M] weights in the loaded rig's target order (sections come back in DFS order)"""
+    out = np.zeros((mw.shape[0], loaded.target_count), np.float32)
+    a, b = _sections_by_node(rig), _sections_by_node(loaded)
+    for node, sb in b.items():
+        sa = a[node]
+        out[:, sb.first_target:sb.first_target + sb.target_count] = mw[:, sa.first_target:sa.first_target + sa.target_count]
+    return out
+
+
+def test_three_skins_and_two_props_round_trip_through_glb(oracle32):
+    """A file with three skinned mesh nodes (three glTF skins over one skeleton) and two un-skinned mesh nodes hanging off
+    joints: the loader + flattener keep EVERY mesh (until round 2 all but the first skin's were dropped) — one section
+    per mesh node in DFS order, one skin per glTF skin in the order the walk meets them, targets and `weights` channels
+    with their own section — and the flat rig evaluates, section by section, to the original's results bit for bit."""
+    rig, loaded, order, perm, crowd, mw = _multi_case()
+    assert np.array_equal(order, perm.astype(np.uint32))
+    a, b = _sections_by_node(rig), _sections_by_node(loaded)
+    assert sorted(a) == sorted(b) and len(loaded.skin_list()) == 3
+    nodes_dfs = [sc.node for sc in loaded.section_list()]
+    assert nodes_dfs == sorted(nodes_dfs), "sections follow the DFS order of their nodes"
+    first = 0
+    for sc in loaded.section_list():   # they tile the vertex array
+        assert sc.first_vertex == first
+        first += sc.vertex_count
+    assert first == loaded.vertex_count == rig.vertex_count
+    for node, sb in b.items():
+        sa = a[node]
+        assert (sa.vertex_count, sa.target_count, sa.skin >= 0) == (sb.vertex_count, sb.target_count, sb.skin >= 0)
+        ra, rb = slice(sa.first_vertex, sa.first_vertex + sa.vertex_count), slice(sb.first_vertex, sb.first_vertex + sb.vertex_count)
+        assert np.array_equal(rig.position[ra], loaded.position[rb]) and np.array_equal(rig.normal[ra], loaded.normal[rb])
+        if sa.skin >= 0:
+            ka, kb = rig.skin_list()[sa.skin], loaded.skin_list()[sb.skin]
+            assert np.array_equal(ka.joint_node, kb.joint_node) and np.array_equal(ka.inverse_bind, kb.inverse_bind)
+            for k in range(rig.set_count):
+                assert np.array_equal(rig.joints[k][ra], loaded.joints[k][rb]) and np.array_equal(rig.weights[k][ra], loaded.weights[k][rb])
+    info = api.validate_rig(loaded)
+    assert (info.skin_count, info.section_count, info.palette_count) == (3, 5, rig.palette_count)
+    want = oracle32.evaluate(rig, crowd.tau, crowd.clip_id, mw)
+    got = oracle32.evaluate(loaded, crowd.tau, crowd.clip_id, _weights_for(loaded, rig, mw))
+    helpers.assert_equal(got.world_rows().view(np.uint32), want.world_rows().view(np.uint32), "world")
+    for node, sb in b.items():
+        sa = a[node]
+        ra, rb = slice(sa.first_vertex, sa.first_vertex + sa.vertex_count), slice(sb.first_vertex, sb.first_vertex + sb.vertex_count)
+        for k in ("position", "normal", "tangent"):
+            helpers.assert_equal(getattr(got, k)[:, rb].view(np.uint32), getattr(want, k)[:, ra].view(np.uint32), f"{k} of the section on node {node}")
+    helpers.assert_equal(got.aabb.view(np.uint32), want.aabb.view(np.uint32), "bounds")
+
+
+@pytest.mark.gpu
+def test_loaded_multi_skin_glb_evaluates_on_the_gpu(oracle32):
+    rig, loaded, _, _, crowd, mw = _multi_case(seed=62)
+    w = _weights_for(loaded, rig, mw)
+    state = synth.CrowdState(crowd.tau, crowd.clip_id, w, None)
+    out = helpers.run_gpu(loaded, state, exact_arithmetic=1)
+    ref = helpers.run_oracle(oracle32, loaded, state)
+    helpers.assert_equal(out["key_index"], ref["key_index"], "key_index")
+    for k in ("world", "palette", "position", "normal", "tangent", "aabb"):
+        helpers.assert_equal(np.asarray(out[k]).view(np.uint32), np.asarray(ref[k]).view(np.uint32), k)

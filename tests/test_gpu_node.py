@@ -54,6 +54,23 @@ def test_node_of_three_shards_equals_the_whole_crowd(oracle32):
         _check_node(node, run_oracle(oracle32, rig, crowd), I, "defaults: ")
 
 
+def test_node_shards_a_rig_with_several_skins_and_props(oracle32):
+    """The rig copy every shard uploads carries skins[] and sections[] (ABI 6): a three-skin avatar with a rigid prop,
+    two shards, every output of every shard against the oracle on the whole crowd."""
+    spec = synth.tiny_spec(seed=33, verts=500, joints=12, nodes=20, clips=2, keys=5, targets=4, sets=2)
+    base = synth.make_rig(spec)
+    rig, tmap = synth.make_multi_rig(base, seed=9)
+    I = 37
+    crowd = synth.make_crowd(spec, base, instances=I, with_root=True)
+    crowd.morph_weights = np.ascontiguousarray(crowd.morph_weights[:, tmap])
+    with api.Node([0, 0], rig, I, exact_arithmetic=1) as node:
+        node.set_clocks(crowd.tau, crowd.clip_id)
+        node.set_morph_weights(crowd.morph_weights)
+        node.set_root_transforms(crowd.root)
+        node.evaluate(sync=True)
+        _check_node(node, run_oracle(oracle32, rig, crowd), I, "multi-skin: ")
+
+
 def test_node_with_more_devices_than_instances(oracle32):
     spec = synth.tiny_spec(seed=12)
     rig = synth.make_rig(spec)
