@@ -67,7 +67,17 @@ int main(int argc, char** argv) {
                 switch (rnd() % 5) { case 0: return 0; case 1: return 0xffffffffu; case 2: return 0x7fffffffu; case 3: return desc->node_count; default: return (uint32_t)rnd(); }
             };
             for (int k = 0, c = 1 + (int)(rnd() % 4); k < c; ++k) {
-                switch (rnd() % 7) {
+                switch (rnd() % 9) {
+                    case 7: if (desc->skin_count) {  // long form (ABI 6): a skin's joint -> node table
+                                const skinrt_skin_desc* sk = &desc->skins[rnd() % desc->skin_count];
+                                if (sk->joint_count) const_cast<uint32_t*>(sk->joint_node)[rnd() % sk->joint_count] = hostile();
+                            } break;
+                    case 8: if (desc->section_count) {  // a section's node / skin / vertex range / target range
+                                skinrt_section_desc* sc = const_cast<skinrt_section_desc*>(&desc->sections[rnd() % desc->section_count]);
+                                switch (rnd() % 6) { case 0: sc->node = hostile(); break; case 1: sc->skin = (int32_t)hostile(); break;
+                                                     case 2: sc->first_vertex = hostile(); break; case 3: sc->vertex_count = hostile(); break;
+                                                     case 4: sc->first_target = hostile(); break; default: sc->target_count = hostile(); }
+                            } break;
                     case 0: if (desc->node_count) const_cast<int32_t*>(desc->parent)[rnd() % desc->node_count] = (int32_t)hostile(); break;
                     case 1: if (desc->joint_count) const_cast<uint32_t*>(desc->joint_node)[rnd() % desc->joint_count] = hostile(); break;
                     case 2: if (desc->vertex_count && desc->set_count) const_cast<uint16_t*>(desc->joints[rnd() % desc->set_count])[rnd() % (desc->vertex_count * 4)] = (uint16_t)hostile(); break;
