@@ -39,10 +39,10 @@ HBM_PEAK = 8.0e12  # B/s, MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 def algorithmic_bytes(rig, instances):
     """B = I*V*36 + I*(J*84 + 4*M) + V*(36 + 24*K) + D, D = dense M*V*36 or
     sparse sum nnz*(4+36).  Shared mesh / morph data counted once per frame."""
-    V, J, M, K = rig.vertex_count, rig.joint_count, rig.target_count, rig.set_count
+    V, J, M, K = rig.vertex_count, rig.palette_count, rig.target_count, rig.set_count  # J: every skin's joints + un-skinned mesh nodes
     d = 0
-    for t in rig.targets:
-        d += V * 36 if t.indices is None else int(t.indices.shape[0]) * 40
+    for t in rig.targets:  # a dense target covers its section (the whole mesh on a one-section rig)
+        d += int(t.position.shape[0]) * 36 if t.indices is None else int(t.indices.shape[0]) * 40
     return instances * V * 36 + instances * (J * 84 + 4 * M) + V * (36 + 24 * K) + d
 
 
@@ -250,6 +250,9 @@ def main():
     ap.add_argument("--advance-clocks", action="store_true",
                     help="every timed frame also advances the instances' clocks on the device (skinrt_advance_clocks, 1/60 s): the frame "
                          "a renderer's loop runs; without it the loop is timed after the main region and reported as frame_loop")
+    ap.add_argument("--multi-skin", action="store_true",
+                    help="the workload's avatar cut into three skins on one skeleton (body / face / hair, each with its own joint order) plus "
+                         "a rigid prop on a bone (synth.make_multi_rig): same vertices, same results for the skinned part; no CPU baseline leg")
     ap.add_argument("--exact", type=int, default=0, choices=[0, 1, 2],
                     help="skinrt_config.exact_arithmetic: 0 chosen per rig, 1 contraction-free kernels (bit-equal to the oracle), 2 FMA kernels")
     args = ap.parse_args()
@@ -299,6 +302,11 @@ def main():
     mine = hi - lo
     rig_data = synth.make_rig(spec)
     crowd_in = synth.make_crowd(spec, rig_data, instances=mine, first=lo)
+    if args.multi_skin:
+        rig_data, target_map = synth.make_multi_rig(rig_data, seed=11)
+        if crowd_in.morph_weights is not None:
+            crowd_in.morph_weights = np.ascontiguousarray(crowd_in.morph_weights[:, target_map])
+        args.no_cpu_baseline = True
 
     ctx = api.Context(device=local_rank, exact_arithmetic=args.exact)
     rig = api.Rig(ctx, rig_data)
@@ -408,9 +416,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{name}: VRM-shaped avatar x instances" if name in ("c3", "c4") else name,
+            "config": {"workload": (f"{name}: VRM-shaped avatar x instances" if name in ("c3", "c4") else name) + (" (multi-skin cut)" if args.multi_skin else ""),
                        "instances_total": total, "instances_per_gpu": mine, "vertices": V,
-                       "joints": rig_data.joint_count, "nodes": rig_data.node_count, "weight_sets": rig_data.set_count,
+                       "joints": rig_data.joint_count, "skins": len(rig_data.skin_list()), "mesh_sections": len(rig_data.section_list()),
+                       "palette_entries": rig_data.palette_count, "nodes": rig_data.node_count, "weight_sets": rig_data.set_count,
                        "morph_targets": rig_data.target_count, "channels": rig_data.max_channels,
                        "stages": "pose+morph+skin+aabb" + ("+allgather(aabb)" if launched else ""),
                        "exact_arithmetic": int(info.exact_arithmetic), "exact_arithmetic_config": args.exact, "parallelism": f"instances sharded x{n_gpus}"},
@@ -422,7 +431,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": skin_ms, "traffic": traffic,
                          "traffic_source": traffic_source},
             "output_placement": crowd.placement,
-            "rig_compile": {"tiles": info.tile_count, "max_tile_joints": info.max_tile_joints,
+            "rig_compile": {"tiles": info.tile_count, "max_tile_joints": info.max_tile_joints, "handed_over_tiles": info.handed_over_tiles,
                             "lds_tiles": info.lds_tiles, "morph_entries": int(info.morph_entries)},
         }
         if exchange is not None:

@@ -190,7 +190,7 @@ pub struct skinrt_rig_info {
     pub skin_count: u32,
     pub section_count: u32,
     pub palette_count: u32,
-    pub reserved: u32,
+    pub handed_over_tiles: u32,
 }
 
 #[repr(C)]

@@ -267,7 +267,10 @@ typedef struct skinrt_rig_info {
     /* ABI 6.  The palette holds every skin's joints one skin after the other, then one entry per distinct node of an
      * un-skinned section (joint matrix = the node's world matrix): palette_count = sum of joint counts + those. */
     uint32_t skin_count, section_count, palette_count;
-    uint32_t reserved;
+    /* tiles (of tile_count) whose joint list is longer than the lists the main skin kernel's LDS ring is sized for: at
+     * most 2 % of the tiles, served whole by the kernel that otherwise takes the instances with many active morph
+     * pairs (typically the tiles that straddle two mesh sections with different skins) */
+    uint32_t handed_over_tiles;
 } skinrt_rig_info;
 
 /* Where a skin / a section lives in the crowd's arrays (skinrt_rig_skin_layout, skinrt_rig_section_layout). */

@@ -142,7 +142,7 @@ class RigInfo(C.Structure):
         ("morph_entries", C.c_uint64), ("device_bytes", C.c_uint64),
         ("exact_arithmetic", C.c_uint32), ("bind_extent", C.c_float),
         ("weight_channel_clips", C.c_uint32), ("skip_weight_sets", C.c_uint32),
-        ("skin_count", C.c_uint32), ("section_count", C.c_uint32), ("palette_count", C.c_uint32), ("reserved", C.c_uint32),
+        ("skin_count", C.c_uint32), ("section_count", C.c_uint32), ("palette_count", C.c_uint32), ("handed_over_tiles", C.c_uint32),
     ]
 
 

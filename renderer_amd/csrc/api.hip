@@ -168,16 +168,7 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg, c
     const uint32_t budget = fixed < 30 * 1024 ? 40 * 1024 - fixed : 10 * 1024;
     p.batch = std::min<uint32_t>(16, std::max<uint32_t>(1, budget / per_inst));
     p.lds_bytes = p.batch * per_inst + fixed;
-    // enough blocks to fill 256 CUs several times over, but ranges long enough to amortise the
-    // per-block vertex load
     const uint64_t want_blocks = 4096;
-    uint64_t range = ((uint64_t)I * std::max<uint32_t>(1, r.T) + want_blocks - 1) / want_blocks;
-    range = std::min<uint64_t>(std::max<uint64_t>(range, p.batch), 256);
-    range = (range + p.batch - 1) / p.batch * p.batch;
-    // the kernel's per-block instance-order tables hold 256 entries: never more than that per block
-    if (range > 256) range = 256 / p.batch * p.batch;
-    p.range = (uint32_t)range;
-    p.ranges = I ? (I + p.range - 1) / p.range : 0;
     // XCD split: as many tile chunks as keep the chunks balanced within 4 %, the rest of the 8
     // XCDs split the ranges (small meshes: every XCD takes all tiles of its own ranges)
     const uint32_t T = std::max<uint32_t>(1, r.T);
@@ -190,21 +181,17 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg, c
         p.tile_chunks = (uint32_t)env.tile_chunks;
     p.tiles_per_chunk = (T + p.tile_chunks - 1) / p.tile_chunks;
     const uint32_t rcs = 8 / p.tile_chunks;
-    p.ranges_per_chunk = (std::max<uint32_t>(1, p.ranges) + rcs - 1) / rcs;
     // ---- self-staging kernel (k_skin2): 4 waves per block, every wave stages its own palette ring
     // and morph slots, 5 blocks (20 compute waves) per CU -> a block must stay under 32 KiB of LDS
-    p.kinds = (r.tile_kind_count[0] ? 1u : 0u) | (r.tile_kind_count[1] ? 2u : 0u) | (r.tile_kind_count[2] ? 4u : 0u);
+    // bit 0 / 1 / 2: tiles of kind 0 / 1 / 2-or-3 exist; bit 3: tiles of kind 3 (all instances handed to k_skin_fix)
+    p.kinds = (r.tile_kind_count[0] ? 1u : 0u) | (r.tile_kind_count[1] ? 2u : 0u) | ((r.tile_kind_count[2] || r.tile_kind_count[3]) ? 4u : 0u) |
+              (r.tile_kind_count[3] ? 8u : 0u);
     p.v2 = (cfg.skin_path == 0 && r.K <= 2 && r.tile_kind_count[2] > 0) ? 1 : 0;
     {
         p.jt2 = std::max<uint32_t>(1, std::min<uint32_t>(r.max_tile_joints2, 21));
-        const uint32_t slots = r.M ? kMorphSlots * kMorphWaveFloats * 4 : 0;
-        const uint32_t tables = kSkin2Range * (16 + 24) + p.max_pairs * 16;  // headers, bounds cells, pair records
-        // the prologue's scratch (counters, masks, order, run starts, header weights) is overlaid on the wave areas
-        const uint32_t scratch = 32 + kSkin2Range * (4 + 2 + 2 + 8 + 8) + 64;
-        auto lds_for = [&](uint32_t look) { return tables + std::max(4 * ((look + 1) * 96u * p.jt2 + slots), scratch); };
-        // blocks per CU the LDS allows (at most 7: the register budget); two instances of lookahead
-        // unless one buys another resident block
-        auto blocks_for = [&](uint32_t look) { return std::min<uint32_t>(7, (160u * 1024) / lds_for(look)); };
+        auto lds_for = [&](uint32_t look) { return skin2_lds_bytes(p.jt2, look, r.M != 0, p.max_pairs); };
+        // blocks per CU the LDS allows; two instances of lookahead unless one buys another resident block
+        auto blocks_for = [&](uint32_t look) { return skin2_blocks_per_cu(lds_for(look)); };
         p.look2 = blocks_for(1) > blocks_for(2) ? 1 : 2;
         p.lds_bytes2 = lds_for(p.look2);
         if (p.lds_bytes2 > 64 * 1024) p.v2 = 0;
@@ -219,6 +206,19 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg, c
         p.run2 = (uint64_t)p.range2 * r.J * 96 <= (2u << 20) ? 1 : std::min<uint32_t>(16, p.tiles_per_chunk);
         if (env.tile_run > 0) p.run2 = std::min<uint32_t>(p.tiles_per_chunk, (uint32_t)env.tile_run);
         p.tiles_per_chunk2 = (p.tiles_per_chunk + p.run2 - 1) / p.run2 * p.run2;
+    }
+    {   // the loader-wave kernel's instance ranges: enough blocks OF ITS OWN TILES to fill 256 CUs several times over (where
+        // k_skin2 takes most tiles, the few left to k_skin want short ranges: 256 instances in a row per block would be a
+        // tail as long as a third of the stage), but ranges long enough to amortise the per-block vertex load
+        const uint32_t own = r.tile_kind_count[0] + r.tile_kind_count[1] + (p.v2 ? 0u : r.tile_kind_count[2] + r.tile_kind_count[3]);
+        uint64_t range = ((uint64_t)I * std::max<uint32_t>(1, own) + want_blocks - 1) / want_blocks;
+        range = std::min<uint64_t>(std::max<uint64_t>(range, std::max<uint32_t>(p.batch, 32)), 256);  // (the grid spans all tiles: not too many empty blocks)
+        range = (range + p.batch - 1) / p.batch * p.batch;
+        // the kernel's per-block instance-order tables hold 256 entries: never more than that per block
+        if (range > 256) range = 256 / p.batch * p.batch;
+        p.range = (uint32_t)range;
+        p.ranges = I ? (I + p.range - 1) / p.range : 0;
+        p.ranges_per_chunk = (std::max<uint32_t>(1, p.ranges) + rcs - 1) / rcs;
     }
     p.exact = r.exact;  // skinrt_config.exact_arithmetic resolved per rig at compile time
     p.normalize = cfg.normalize_outputs ? 1 : 0;
@@ -423,7 +423,7 @@ int skinrt_create_crowd(skinrt_ctx* ctx, skinrt_rig* rig, uint32_t instances, sk
         {&c->mw_eff, h.weight_channel_clips ? I * h.M * 4 : 0},  // morph weights after the weights channels (pose stage)
         {&c->world, I * h.N * 48}, {&c->palette, I * h.J * 96}, {&c->keyidx, I * h.Cmax * 4},
         {&c->aabb_part, I * h.T * 24}, {&c->aabb, I * 24},      // bounds per (instance, tile)
-        {&c->fix, h.M ? ((size_t)h.T + 3) / 4 * 16 + I * h.T * 4 : 0},  // per-tile work lists of k_skin_fix
+        {&c->fix, (h.M || h.tile_kind_count[3]) ? ((size_t)h.T + 3) / 4 * 16 + I * h.T * 4 : 0},  // per-tile work lists of k_skin_fix
         {&c->amask, h.M ? I * ((h.M + 63) / 64) * 8 : 0},               // non-zero morph weights as bit rows
     };
     for (auto& it : plan) {

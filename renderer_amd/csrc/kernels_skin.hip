@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
     // joint locality) by the LDSPAL=false launch that gathers the palette from L2
     {
         const uint32_t kind = rig.tile_lds[tile];  // 2: short joint list (k_skin2's tiles unless switched off)
-        if (LDSPAL ? !(kind == 1 || (kind == 2 && !plan.v2)) : kind != 0) return;
+        if (LDSPAL ? !(kind == 1 || (kind >= 2 && !plan.v2)) : kind != 0) return;  // (3: kind 2 whose instances k_skin_fix takes)
     }
     const uint32_t i0 = rng * plan.range;
     const uint32_t i1 = min(cr.I, i0 + plan.range);
@@ -862,9 +862,10 @@ __global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdD
     __shared__ uint32_t wave_n[kClassifyRounds * 4];  // [round][wave]
     __shared__ uint32_t block_base;
     const uint32_t tile = blockIdx.x / slices, slice = blockIdx.x - tile * slices;
-    if (tile >= rig.T || rig.tile_lds[tile] != 2) return;
+    if (tile >= rig.T || rig.tile_lds[tile] < 2) return;
+    const bool all = rig.tile_lds[tile] == 3;  // a joint list longer than k_skin2's ring is sized for: every instance is listed
     const uint32_t pbeg = rig.tile_pair_start[tile], np = rig.tile_pair_start[tile + 1] - pbeg;
-    if (np == 0) return;
+    if (np == 0 && !all) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t i0 = slice * (kClassifyRounds * 256u);
     uint32_t mine = 0;                    // bit r: my instance of round r is slow
@@ -873,7 +874,8 @@ __global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdD
     for (uint32_t r = 0; r < kClassifyRounds; ++r) {
         const uint32_t inst = i0 + r * 256u + tid;
         bool slow = false;
-        if (inst < cr.I) slow = classify_pairs(rig.pairs + pbeg, np, cr.amask + (size_t)inst * words, words, cr.mw + (size_t)inst * rig.M, rig.sparse_pairs != 0).slow;
+        if (inst < cr.I)
+            slow = all || classify_pairs(rig.pairs + pbeg, np, cr.amask + (size_t)inst * words, words, cr.mw + (size_t)inst * rig.M, rig.sparse_pairs != 0).slow;
         const uint64_t bslow = __ballot(slow);
         if (lane == 0) wave_n[r * 4 + wave] = (uint32_t)__popcll(bslow);
         rank[r] = (uint32_t)__popcll(bslow & ((1ull << lane) - 1ull));
@@ -1460,6 +1462,19 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
                     plan.run2 == 0 || plan.tiles_per_chunk2 % plan.run2 != 0 || plan.tiles_per_chunk2 < plan.tiles_per_chunk))
         return hipErrorInvalidValue;
     hipError_t e = hipSuccess;
+    // the loader-wave kernel: tiles of kinds 1 and 0, and kind 2 as well where the self-staging kernel is switched off.
+    // Its LDS need is checked only when it is launched at all (skinrt_create_crowd refuses such rigs).
+    const bool others = (plan.kinds & 3u) != 0;
+    auto launch_k_skin = [&](hipStream_t ks) -> hipError_t {
+        hipError_t ke = hipSuccess;
+        if (plan.lds_bytes > 64 * 1024) return hipErrorInvalidValue;
+        if ((plan.kinds & 2u) || (!plan.v2 && (plan.kinds & 4u)))
+            ke = plan.exact ? launch_skin_k<true, true>(rig, cr, plan, ks) : launch_skin_k<false, true>(rig, cr, plan, ks);
+        if (ke == hipSuccess && (plan.kinds & 1u))
+            ke = plan.exact ? launch_skin_k<true, false>(rig, cr, plan, ks) : launch_skin_k<false, false>(rig, cr, plan, ks);
+        return ke;
+    };
+    bool others_done = false;
     // tiles of kind 2 (short joint lists): the self-staging kernel unless it is switched off
     if (plan.v2 && (plan.kinds & 4u)) {
         // Work lists first (k_classify), then the two consumers at the same time: k_skin_fix (latency-bound, few
@@ -1468,28 +1483,36 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         // 0.5 ms (C3).  Fork / join by events: the caller's stream sees the stage as one unit.
         // (a tile needs at least 3 pairs to hand an instance over: without such a tile there is no list to build and no
         // k_skin_fix to launch; the active-pair bit rows are k_skin2's own input either way)
-        const bool lists = cr.fix && plan.max_pairs > 2;
-        const bool side = lists && conc.side != nullptr && conc.fork != nullptr && conc.join != nullptr;
+        // The tiles k_skin2 leaves to k_skin (few: long joint lists) go the same way, in front of k_skin_fix on the side
+        // stream, instead of as a tail behind k_skin2.
+        const bool lists = cr.fix && (plan.max_pairs > 2 || (plan.kinds & 8u));
+        const bool want_fix = lists && !(SKINRT_ABLATE & 32);
+        const bool side = (want_fix || others) && conc.side != nullptr && conc.fork != nullptr && conc.join != nullptr;
         if (cr.fix) {
             e = hipMemsetAsync(cr.fix, 0, (size_t)rig.T * 4, s);  // empty work lists
             if (e != hipSuccess) return e;
             const uint32_t slices = (cr.I + kClassifyRounds * 256u - 1) / (kClassifyRounds * 256u);
             if ((uint64_t)rig.T * slices > 0x7fffffffull) return hipErrorInvalidValue;
-            const uint32_t words = (rig.M + 63) / 64;
-            if (!cr.amask || (uint64_t)cr.I * words > 0x7fffffffull) return hipErrorInvalidValue;
-            hipLaunchKernelGGL(k_active_mask, dim3((cr.I * words + 3) / 4), dim3(256), 0, s, cr, rig.M, words);
+            const uint32_t words = (rig.M + 63) / 64;  // 0: a rig without morph targets whose long-list tiles go to k_skin_fix
+            if ((words && !cr.amask) || (uint64_t)cr.I * words > 0x7fffffffull) return hipErrorInvalidValue;
+            if (words) hipLaunchKernelGGL(k_active_mask, dim3((cr.I * words + 3) / 4), dim3(256), 0, s, cr, rig.M, words);
             if (lists) hipLaunchKernelGGL(k_classify, dim3(rig.T * slices), dim3(256), 0, s, rig, cr, slices, words);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
-            if (side && (e = hipEventRecord(conc.fork, s)) != hipSuccess) return e;  // the lists are complete here
         }
-        auto launch_fix = [&]() -> hipError_t {
+        if (side && (e = hipEventRecord(conc.fork, s)) != hipSuccess) return e;  // the pose stage's outputs and the lists are complete here
+        auto launch_fix = [&]() -> hipError_t {  // everything that runs beside k_skin2
             hipStream_t fs = s;
             hipError_t fe;
             if (side) {
                 if ((fe = hipStreamWaitEvent(conc.side, conc.fork, 0)) != hipSuccess) return fe;
                 fs = conc.side;
+                if (others) {
+                    others_done = true;
+                    if ((fe = launch_k_skin(fs)) != hipSuccess) return fe;
+                }
             }
+            if (!want_fix) return side ? hipEventRecord(conc.join, conc.side) : hipSuccess;
             // one block per (tile, chunk lane).  Lists are uneven (tiles with many pairs hand over most), so there are
             // enough lanes that the longest list is a few chunks per block; blocks past a list's end leave at once
             const uint32_t lanes = std::min((cr.I + kFixChunk - 1) / kFixChunk, std::max(1u, conc.fix_blocks / rig.T));
@@ -1510,8 +1533,8 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
             if (side) return hipEventRecord(conc.join, conc.side);
             return hipSuccess;
         };
-        const bool want_fix = lists && !(SKINRT_ABLATE & 32);
-        if (want_fix && !conc.skin2_first && (e = launch_fix()) != hipSuccess) return e;
+        const bool beside = want_fix || (side && others);
+        if (beside && !conc.skin2_first && (e = launch_fix()) != hipSuccess) return e;
         const dim3 grid(8u * plan.tiles_per_chunk2 * plan.ranges_per_chunk2), block(kSkin2Threads);
 #define SKINRT_LAUNCH2(EX, KK, LL, SK)                                                                                     \
     do {                                                                                                                   \
@@ -1529,19 +1552,14 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
 #undef SKINRT_LAUNCH2K
 #undef SKINRT_LAUNCH2
         e = hipGetLastError();
-        if (e == hipSuccess && want_fix && conc.skin2_first) e = launch_fix();
-        if (side && want_fix) {  // join even after a failed launch: the side stream's work may already be enqueued
+        if (e == hipSuccess && beside && conc.skin2_first) e = launch_fix();
+        if (side && beside) {  // join even after a failed launch: the side stream's work may already be enqueued
             const hipError_t je = hipStreamWaitEvent(s, conc.join, 0);
             if (e == hipSuccess) e = je;
         }
     }
-    // the loader-wave kernel's LDS need is checked only when it is launched at all (skinrt_create_crowd refuses such rigs)
-    const bool need_k_skin = (plan.kinds & 3u) || (!plan.v2 && (plan.kinds & 4u));
-    if (e == hipSuccess && need_k_skin && plan.lds_bytes > 64 * 1024) return hipErrorInvalidValue;
-    if (e == hipSuccess && ((plan.kinds & 2u) || (!plan.v2 && (plan.kinds & 4u))))
-        e = plan.exact ? launch_skin_k<true, true>(rig, cr, plan, s) : launch_skin_k<false, true>(rig, cr, plan, s);
-    if (e == hipSuccess && (plan.kinds & 1u))
-        e = plan.exact ? launch_skin_k<true, false>(rig, cr, plan, s) : launch_skin_k<false, false>(rig, cr, plan, s);
+    const bool need_k_skin = others || (!plan.v2 && (plan.kinds & 4u));
+    if (e == hipSuccess && need_k_skin && !others_done) e = launch_k_skin(s);
     return e;
 }
 

@@ -502,6 +502,43 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
         std::vector<PairTmp>().swap(per_tile[t]);
     }
     r.mblock.resize(r.mblock.size() + 256, 0.0f);  // slack so a full-wave 16-byte piece never reads past the pool
+
+    // k_skin2 sizes every block's palette ring by the LONGEST joint list among its tiles, and the ring decides how many
+    // blocks a CU holds.  A few long lists — tiles that straddle two mesh sections with different skins, a hand among
+    // torso tiles — must not cost every tile a resident block: if handing at most 2 % of the kernel's tiles over to
+    // k_skin_fix (kind 3: every instance of the tile goes on its work list; that kernel stages any list of up to 21
+    // joints and runs beside k_skin2 in what k_skin2 leaves free) buys one, do it.
+    // (C3's avatar cut into three skins: lists of 8 except three straddling tiles with 15; 4 -> 5 blocks per CU.)
+    if (K <= 2 && r.tile_kind_count[2] > 0) {
+        uint32_t hist[22] = {0};
+        for (uint32_t t = 0; t < T; ++t)
+            if (r.tile_lds[t] == 2) hist[r.tile_joint_start[t + 1] - r.tile_joint_start[t]] += 1;
+        // what the plan (api.hip: plan_skin) will make of a ring sized for lists of jt joints: resident blocks first, and at
+        // equal blocks two instances of palette lookahead rather than one
+        auto blocks = [&](uint32_t jt) {
+            const uint32_t b1 = skin2_blocks_per_cu(skin2_lds_bytes(jt, 1, M != 0, r.max_tile_pairs));
+            const uint32_t b2 = skin2_blocks_per_cu(skin2_lds_bytes(jt, 2, M != 0, r.max_tile_pairs));
+            return b1 > b2 ? 2 * b1 : 2 * b2 + 1;
+        };
+        const uint32_t full = r.max_tile_joints2, tiles2 = r.tile_kind_count[2];
+        uint32_t cap = full, moved = 0;
+        for (uint32_t c = full, gone = 0; c > 1; --c) {
+            gone += hist[c];  // tiles with lists longer than c - 1
+            if ((uint64_t)gone * 50 > tiles2) break;
+            if (blocks(c - 1) > blocks(cap)) { cap = c - 1; moved = gone; }
+        }
+        if (cap < full) {
+            r.max_tile_joints2 = 0;
+            for (uint32_t t = 0; t < T; ++t) {
+                if (r.tile_lds[t] != 2) continue;
+                const uint32_t n = r.tile_joint_start[t + 1] - r.tile_joint_start[t];
+                if (n > cap) r.tile_lds[t] = 3;
+                else r.max_tile_joints2 = std::max(r.max_tile_joints2, n);
+            }
+            r.tile_kind_count[2] -= moved;
+            r.tile_kind_count[3] += moved;
+        }
+    }
 }
 
 int compile_rig(const skinrt_rig_desc* desc, const skinrt_config* cfg, CompiledRig& out, std::string& err) {
@@ -534,6 +571,7 @@ void fill_rig_info(const CompiledRig& r, uint64_t device_bytes, skinrt_rig_info*
     info->skin_count = (uint32_t)r.skins.size();
     info->section_count = (uint32_t)r.sections.size();
     info->palette_count = r.J;
+    info->handed_over_tiles = r.tile_kind_count[3];
 }
 
 }  // namespace skinrt

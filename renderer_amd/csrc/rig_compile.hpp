@@ -44,6 +44,7 @@ struct MorphPair {
 #endif
 constexpr uint32_t kSkin2Range = SKINRT_RANGE2;         // instances per block of the self-staging skinning kernel
 constexpr uint32_t kMorphWaveFloats = 576;    // one wave's share of a dense pair = one LDS slot
+
 constexpr uint32_t kMorphDenseMin = 57;       // touched vertices from which a pair is stored dense
                                               // (a sparse region, 64 + 56*9 floats, still fits a slot)
 #ifndef SKINRT_SPARSE_SLOTS
@@ -53,6 +54,21 @@ constexpr uint32_t kMorphDenseMin = 57;       // touched vertices from which a p
 #define SKINRT_MORPH_SLOTS 2
 #endif
 constexpr uint32_t kMorphSlots = SKINRT_MORPH_SLOTS;  // LDS slots per wave: active pairs streamed per instance
+
+// LDS of one k_skin2 block (kernels_skin.hip: block tables, then per wave {palette ring of look + 1 slots, morph slots};
+// the prologue's scratch is overlaid on the wave areas) and the blocks per CU it allows (at most 7: the register budget).
+// Shared by the plan (api.hip) and by the rig compiler, which sizes the ring by the joint lists it lets the kernel take.
+inline uint32_t skin2_lds_bytes(uint32_t tile_joints, uint32_t look, bool morph, uint32_t max_pairs) {
+    const uint32_t slots = morph ? kMorphSlots * kMorphWaveFloats * 4 : 0;
+    const uint32_t tables = kSkin2Range * (16 + 24) + max_pairs * 16;  // headers, bounds cells, pair records
+    const uint32_t scratch = 32 + kSkin2Range * (4 + 2 + 2 + 8 + 8) + 64;
+    const uint32_t waves = 4 * ((look + 1) * 96u * tile_joints + slots);
+    return tables + (waves > scratch ? waves : scratch);
+}
+inline uint32_t skin2_blocks_per_cu(uint32_t lds_bytes) {
+    const uint32_t b = (160u * 1024) / (lds_bytes ? lds_bytes : 1u);
+    return b < 7 ? b : 7;
+}
 
 // who drives morph target m of an instance playing a given clip: a SKINRT_PATH_WEIGHTS channel, or nobody (chan < 0)
 struct WeightSrc {
@@ -100,8 +116,9 @@ struct CompiledRig {
     std::vector<uint16_t> lidx;         // [T][4K][256] tile-local joint index (LDS tiles) or global joint id
     std::vector<uint32_t> tile_joint_start;  // [T+1]
     std::vector<uint32_t> tile_joints;       // concatenated tile joint lists (global ids, ascending)
-    std::vector<uint8_t> tile_lds;           // [T] 0 = joint list exceeds kTileJointCap, 1 = fits, 2 = at most 21 joints
-    uint32_t tile_kind_count[3] = {0, 0, 0}; // tiles of each kind
+    std::vector<uint8_t> tile_lds;           // [T] 0 = joint list exceeds kTileJointCap, 1 = fits, 2 = at most 21 joints, 3 = as 2 but
+                                             // longer than the lists k_skin2's palette ring is sized for: all its instances go to k_skin_fix
+    uint32_t tile_kind_count[4] = {0, 0, 0, 0}; // tiles of each kind
     uint32_t max_tile_joints = 0;            // over LDS tiles
     uint32_t max_tile_joints_any = 0;
     uint32_t max_tile_joints2 = 0;           // over the self-staging kernel's tiles (kind 2): <= 21

@@ -202,3 +202,55 @@ def test_weights_channels_drive_their_own_section(oracle32):
     ref = run_oracle(oracle32, rig, multi)
     _check_all(got, ref, exact_skin=True, tag="weights channels per section:")
     assert (multi.clip_id == 1).any() and (multi.clip_id == 2).any()
+
+
+@pytest.mark.parametrize("skin_path", [0, 1])
+def test_tiles_that_straddle_two_skins_are_handed_to_the_fix_kernel(oracle32, skin_path, targets=6):
+    """The main skin kernel sizes every block's palette ring by the longest joint list among its tiles; the rig compiler
+    hands the few tiles with much longer lists — here the ones that straddle two sections with different skins — to
+    the kernel that serves the work lists, whole (skinrt_rig_info.handed_over_tiles), where that buys a resident block.
+    Results are the oracle's bit for bit either way, over frames that reuse the crowd, and with the main kernel switched
+    off (skin_path = 1: the loader-wave kernel takes those tiles like any other)."""
+    spec = synth.scaled(synth.CONFIGS["c3"], verts=256 * 120 + 77, targets=targets, keys=4)
+    base = synth.make_rig(spec)
+    rig, tmap = synth.make_multi_rig(base, seed=4, fractions=(0.37, 0.33, 0.3), rigid_frac=0.0, rigid_sections=0)
+    info = api.validate_rig(rig)
+    one = api.validate_rig(base)
+    assert one.handed_over_tiles == 0 and one.max_tile_joints <= 9
+    assert 1 <= info.handed_over_tiles <= 2 and info.max_tile_joints > 12, (info.handed_over_tiles, info.max_tile_joints)
+    I = 173
+    with api.Context(exact_arithmetic=1, skin_path=skin_path) as ctx:
+        r = api.Rig(ctx, rig)
+        c = api.Crowd(ctx, r, I)
+        for frame in range(2):
+            crowd, multi = _multi_crowd(synth.scaled(spec, seed=spec.seed + frame), base, tmap, I)
+            c.set_clocks(multi.tau, multi.clip_id)
+            if multi.morph_weights is not None:
+                c.set_morph_weights(multi.morph_weights)
+            c.evaluate(abi.STAGE_ALL, sync=True)
+            ref = oracle32.evaluate(rig, multi.tau, multi.clip_id, multi.morph_weights, want=("position", "normal", "tangent", "aabb"))
+            assert_equal(c.positions().view(np.uint32), ref.position.view(np.uint32), f"frame {frame}: position")
+            assert_equal(c.normals().view(np.uint32), ref.normal.view(np.uint32), f"frame {frame}: normal")
+            assert_equal(c.tangents().view(np.uint32), ref.tangent.view(np.uint32), f"frame {frame}: tangent")
+            assert_equal(c.aabbs().view(np.uint32), ref.aabb.view(np.uint32), f"frame {frame}: bounds")
+        c.close(); r.close()
+
+
+def test_a_long_joint_list_on_a_rig_without_morph_targets(oracle32):
+    """The same hand-over where there are no morph targets at all (no active-pair rows, no pair lists: the work lists
+    alone drive that kernel): one tile of an otherwise short-listed mesh is bound to 20 joints, which would cost every
+    block of the main kernel a seventh of the CU (6 instead of 7 resident blocks)."""
+    spec = synth.scaled(synth.CONFIGS["c3"], verts=256 * 90 + 5, targets=0, keys=4)
+    rig = synth.make_rig(spec)
+    assert rig.target_count == 0 and rig.joint_count >= 40
+    lo = 256 * 17
+    v = np.arange(256)
+    rig.joints[0][lo:lo + 256] = ((v[:, None] * 4 + np.arange(4)[None, :]) % 20 + 11).astype(np.uint16)
+    rig.weights[0][lo:lo + 256] = np.array([0.4, 0.3, 0.2, 0.1], np.float32)
+    info = api.validate_rig(rig)
+    assert info.handed_over_tiles == 1 and info.max_tile_joints == 20, (info.handed_over_tiles, info.max_tile_joints)
+    I = 300
+    crowd = synth.make_crowd(spec, rig, instances=I)
+    got = run_gpu(rig, crowd, exact_arithmetic=1)
+    ref = run_oracle(oracle32, rig, crowd)
+    _check_all(got, ref, exact_pose=True, exact_skin=True, tag="long list, no targets:")
