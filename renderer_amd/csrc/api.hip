@@ -64,6 +64,7 @@ struct EnvKnobs {
     int range2 = 0;              // SKINRT_RANGE2: instances per k_skin2 block (0: chosen per crowd)
     int tile_run = 0;            // SKINRT_TILE_RUN: tiles per run dealt to an XCD (0: chosen per crowd)
     int skip_sets = -1;          // SKINRT_SKIP_SETS: force the kernels that stop a wave after its last used weight set on / off
+    int lds_pad = 0;             // SKINRT_LDS_PAD: bytes of unused LDS added to every k_skin2 block (occupancy experiments)
     static int num(const char* name, int dflt) {
         const char* v = std::getenv(name);
         return v ? std::atoi(v) : dflt;
@@ -78,6 +79,7 @@ struct EnvKnobs {
         range2 = num("SKINRT_RANGE2", 0);
         tile_run = num("SKINRT_TILE_RUN", 0);
         skip_sets = num("SKINRT_SKIP_SETS", -1);
+        lds_pad = std::max(0, std::min(32 * 1024, num("SKINRT_LDS_PAD", 0)));
     }
 };
 
@@ -193,7 +195,7 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg, c
         // blocks per CU the LDS allows; two instances of lookahead unless one buys another resident block
         auto blocks_for = [&](uint32_t look) { return skin2_blocks_per_cu(lds_for(look)); };
         p.look2 = blocks_for(1) > blocks_for(2) ? 1 : 2;
-        p.lds_bytes2 = lds_for(p.look2);
+        p.lds_bytes2 = lds_for(p.look2) + (uint32_t)env.lds_pad;
         if (p.lds_bytes2 > 64 * 1024) p.v2 = 0;
         uint64_t r2 = ((uint64_t)I * std::max<uint32_t>(1, r.T) + want_blocks - 1) / want_blocks;
         p.range2 = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(r2, 1), kSkin2Range);
