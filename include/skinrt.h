@@ -314,7 +314,21 @@ SKINRT_API uint32_t skinrt_build_flags(void);
 SKINRT_API const char* skinrt_last_error(void);
 
 /* Create a context on config->device with its own HIP stream.
- * Replaces wgpu device/queue acquisition for this path (renderer/src/state.rs:94-127). */
+ * Replaces wgpu device/queue acquisition for this path (renderer/src/state.rs:94-127).
+ *
+ * Environment.  skinrt_init reads the variables below ONCE (nothing is read per frame); they move work between
+ * streams / blocks / launch orders for measurements (tools/, profiles/) and never change a result.  Unset = the
+ * product's choice, which is what every number in DESIGN.md is measured with.
+ *   SKINRT_FIX_STREAM  0: the skin stage's kernels one after the other on the ctx stream (default 1: k_skin_fix beside k_skin2)
+ *   SKINRT_FIX_PRIO    priority of that side stream: -1 most urgent, 0 default, 1 least urgent (default)
+ *   SKINRT_FIX_ORDER   1: enqueue k_skin2 before k_skin_fix (default 0)
+ *   SKINRT_FIX_BLOCKS  about this many k_skin_fix blocks (default 32768)
+ *   SKINRT_POSE_PRE    0: sample channels inside the pose kernels, no node-major scratch (default 1)
+ *   SKINRT_TILE_CHUNKS 1 / 2 / 4 / 8 tile chunks over the XCDs (default: chosen per rig)
+ *   SKINRT_RANGE2      instances per k_skin2 block, at most 80 (default: chosen per crowd)
+ *   SKINRT_TILE_RUN    tiles per run dealt to an XCD (default: chosen per crowd)
+ *   SKINRT_SKIP_SETS   1 / 0: force the kernels that stop a wave after its last used weight set on / off
+ *   SKINRT_LDS_PAD     bytes of unused LDS added to every k_skin2 block, at most 32768 (occupancy experiments) */
 SKINRT_API int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx);
 SKINRT_API int skinrt_destroy_ctx(skinrt_ctx* ctx);
 
