@@ -275,6 +275,25 @@ __device__ __forceinline__ void morph_pair(const float* src, bool dense, uint32_
     }
 }
 
+// The load half of morph_pair: this lane's nine deltas of one pair; false = the pair does not touch the lane's vertex
+// (compacted pairs only: a vertex outside the target's index list is not added to at all, not even a zero).
+__device__ __forceinline__ bool morph_load(const float* src, bool dense, uint32_t tid, float (&d)[9]) {
+    if (dense) {
+#pragma unroll
+        for (int x = 0; x < 9; ++x) d[x] = src[x * 64 + (tid & 63)];
+        return true;
+    }
+    const uint32_t slot = reinterpret_cast<const uint8_t*>(src)[tid];
+#pragma unroll
+    for (int x = 0; x < 9; ++x) d[x] = 0.0f;
+    if (slot) {
+        const float* dp = src + kTileVerts / 4 + (slot - 1) * 9;
+#pragma unroll
+        for (int x = 0; x < 9; ++x) d[x] = dp[x];
+    }
+    return slot != 0;
+}
+
 // 16 bytes per lane, global (uniform base + lane byte offset + IMM) -> LDS (lds_base + IMM + lane*16),
 // with no register destination.  Written as asm: the compiler's wait-count pass treats an LDS-DMA
 // it can see as aliasing every later LDS read and answers with s_waitcnt vmcnt(0), which here would
@@ -908,7 +927,17 @@ __global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdD
 // palette rows of the tile's joints are staged in LDS (at most 126 16-byte pieces), the active
 // pairs' deltas come by plain loads (L2-resident), and resident blocks cover each other's latency.
 // Same arithmetic, in the same order, as the staged kernels (a13: targets ascending).
+#ifndef SKINRT_FIX_ABLATE
+#define SKINRT_FIX_ABLATE 0
+#endif
 constexpr uint32_t kFixChunk = 8;
+// instances of a chunk morphed together (kFixChunk is a multiple): 0 = the product's choice per weight-set count — 4 for
+// K = 1 (119 VGPRs: fits beside k_skin2's five blocks), 2 for K = 2 (4 needs 131-134 VGPRs and no longer fits beside
+// k_skin2's four: C5 +8 %; 2 against 1: C5 -1.7 %, 10.49 / 10.47 / 10.46 -> 10.30 / 10.33 / 10.18).  C3 does not care
+// (4.21-4.24 ms with 1, 2 or 4); a face under tracking (tools/exp_face.py: 52 targets all active) 6.90 -> 5.58 ms with 4.
+#ifndef SKINRT_FIX_BATCH
+#define SKINRT_FIX_BATCH 0
+#endif
 constexpr uint32_t kFixLdsBytes = 2 * 128 * 16 + 4 * 6 * 4 + 32 + 64 * sizeof(MorphPair);  // of the block's dynamic LDS
 // fb = this block's index among the kernel's `fix_blocks` blocks (a multiple of 8 * ceil(T / 8))
 template <int AR, int K, bool SKIP>
@@ -916,6 +945,8 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
     constexpr bool EXACT = AR != 0, NEXACT = AR == 1;  // AR 2: positions contraction-free, normals / tangents fused
+    constexpr uint32_t kFixBatch = SKINRT_FIX_BATCH ? SKINRT_FIX_BATCH : (K == 1 ? 4u : 2u);
+    static_assert(kFixChunk % kFixBatch == 0, "a chunk is a whole number of batches");
     f4 (*pal_s)[128] = reinterpret_cast<f4 (*)[128]>(smem);                            // [2][128]
     float (*part)[6] = reinterpret_cast<float (*)[6]>(pal_s + 2);                        // [4][6] (+ 32 B pad)
     MorphPair* pairs_l = reinterpret_cast<MorphPair*>(reinterpret_cast<char*>(part) + 4 * 6 * 4 + 32);  // the tile's first 64 pair records
@@ -956,77 +987,125 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
     __syncthreads();
     const uint32_t* list = cr.fix_inst + (size_t)tile * cr.I;
     uint32_t flip = 0;  // palette staging buffer in use
-    for (uint32_t e0 = chunk_lane * kFixChunk; e0 < count; e0 += chunk_lanes * kFixChunk) {
+    const uint32_t np64 = min(pend - pbeg, 64u);
+    // kFixBatch instances at a time: the morph walks the tile's pairs ONCE for all of them — a pair's deltas are read
+    // (from L2) once per batch, not once per instance that uses it.  Where most pairs are active (a face under tracking:
+    // 20 pairs per tile, all non-zero) those reads were the kernel's time.  Per instance the pairs are still applied in
+    // ascending order (a13), so the sums are the same.  The NEXT batch's palette pieces and pair weights are requested
+    // while this one is worked on, into the registers this batch has just finished with.
+    const uint32_t stride = chunk_lanes * kFixChunk;
+    uint32_t e0 = chunk_lane * kFixChunk;
+    uint32_t ents = 0;  // the chunk's instances in one load (lane k = entry e0 + k)
+    if (e0 + lane < count && lane < kFixChunk) ents = list[e0 + lane];
+    uint32_t inst[kFixBatch];
+    f4 piece[kFixBatch];
+    float mwq[kFixBatch];  // lane q: weight of pair q (first 64 pairs) for instance b; 0 for b past the batch's end
+    {
+        const uint32_t nb0 = min(kFixBatch, min(count, e0 + kFixChunk) - e0);
+#pragma unroll
+        for (uint32_t b = 0; b < kFixBatch; ++b) {
+            inst[b] = __builtin_amdgcn_readlane(ents, b < nb0 ? b : 0u);
+            piece[b] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (b < nb0 && tid < npieces) piece[b] = pal_g[(size_t)inst[b] * rig.J * 6 + joff];
+            mwq[b] = (b < nb0 && lane < np64) ? cr.mw[(size_t)inst[b] * M + pairs_l[lane].target] : 0.0f;
+        }
+    }
+    for (; e0 < count; e0 += stride) {
         const uint32_t e1 = min(count, e0 + kFixChunk);
-        // the chunk's instances in one load (lane k = entry e0 + k)
-        uint32_t ents = 0;
-        if (e0 + lane < e1 && lane < kFixChunk) ents = list[e0 + lane];
-        // palette piece and pair weights of the NEXT entry, requested while the current one is worked on
-        f4 piece_next = {0.0f, 0.0f, 0.0f, 0.0f};
-        float mwq_next = 0.0f;
-        bool have_next = false;
-        for (uint32_t e = e0; e < e1; ++e) {
-            const uint32_t inst = __builtin_amdgcn_readlane(ents, e - e0);
-            // stage this instance's palette rows; the buffers alternate, so the one barrier below
-            // also separates the previous entry's reads of this buffer from these writes
-            f4* ps = pal_s[flip];
-            flip ^= 1u;
-            const float* mwg = cr.mw + (size_t)inst * M;
-            // the first 64 pairs: one parallel fetch of their weights (lane q = pair q), then only the
-            // active ones are visited, ascending — not one dependent load chain per pair
-            const uint32_t np64 = min(pend - pbeg, 64u);
-            f4 piece = piece_next;
-            float mwq = mwq_next;
-            if (!have_next) {
-                if (tid < npieces) piece = pal_g[(size_t)inst * rig.J * 6 + joff];
-                mwq = lane < np64 ? mwg[pairs_l[lane].target] : 0.0f;
+        const uint32_t e0n = e0 + stride;  // this block's next chunk
+        uint32_t ents_next = 0;
+        if (e0n + lane < count && lane < kFixChunk) ents_next = list[e0n + lane];
+        for (uint32_t b0 = e0; b0 < e1; b0 += kFixBatch) {
+            const uint32_t nb = min(kFixBatch, e1 - b0);
+            // the batch after this one: the rest of the chunk, else the head of the next chunk
+            uint32_t nnb = 0, inst_n[kFixBatch];
+            if (b0 + kFixBatch < e1) {
+                nnb = min(kFixBatch, e1 - b0 - kFixBatch);
+#pragma unroll
+                for (uint32_t b = 0; b < kFixBatch; ++b) inst_n[b] = __builtin_amdgcn_readlane(ents, (b0 - e0 + kFixBatch + (b < nnb ? b : 0u)) & 63u);
+            } else {
+                if (e0n < count) nnb = min(kFixBatch, min(count, e0n + kFixChunk) - e0n);
+#pragma unroll
+                for (uint32_t b = 0; b < kFixBatch; ++b) inst_n[b] = __builtin_amdgcn_readlane(ents_next, b < nnb ? b : 0u);
             }
-            have_next = e + 1 < e1;
-            if (have_next) {
-                const uint32_t inst2 = __builtin_amdgcn_readlane(ents, (e + 1 - e0) & 63u);
-                if (tid < npieces) piece_next = pal_g[(size_t)inst2 * rig.J * 6 + joff];
-                mwq_next = lane < np64 ? cr.mw[(size_t)inst2 * M + pairs_l[lane].target] : 0.0f;
+            float p[kFixBatch][3], n[kFixBatch][3], t[kFixBatch][3];
+            uint64_t act[kFixBatch];
+            uint64_t any = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < kFixBatch; ++b) {
+#pragma unroll
+                for (int x = 0; x < 3; ++x) { p[b][x] = p0[x]; n[b][x] = n0[x]; t[b][x] = t0[x]; }
+                act[b] = (SKINRT_FIX_ABLATE & 1) ? 0ull : __ballot(mwq[b] != 0.0f);
+                any |= act[b];
             }
-            if (tid < npieces) ps[tid] = piece;
-            float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
-#ifndef SKINRT_FIX_ABLATE
-#define SKINRT_FIX_ABLATE 0
-#endif
-            for (uint64_t act = (SKINRT_FIX_ABLATE & 1) ? 0ull : __ballot(mwq != 0.0f); act; act &= act - 1) {
-                const uint32_t q = (uint32_t)__builtin_ctzll(act);
-                const float mw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mwq), q));
+            for (; any; any &= any - 1) {
+                const uint32_t q = (uint32_t)__builtin_ctzll(any);
                 const MorphPair mp = pairs_l[q];
                 if (!((mp.wave_mask >> wave) & 1u)) continue;  // nothing of this wave's 64 vertices moves: adds exactly 0
-                const bool dense = mp.dense != 0;
-                morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
-            }
-            for (uint32_t q = pbeg + 64; q < pend; ++q) {
-                const MorphPair mp = rig.pairs[q];
-                const float mw = mwg[mp.target];
-                if (mw == 0.0f || !((mp.wave_mask >> wave) & 1u)) continue;  // wave-uniform; adds exactly 0
-                const bool dense = mp.dense != 0;
-                morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p, n, t);
-            }
-            lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
-            float op[3];
-            skin_store<EXACT, NEXACT, K, SKIP>(LdsPal{ps}, w, li, ninf, p, n, t, normalize, valid && !(SKINRT_FIX_ABLATE & 2), out, (size_t)inst * rig.V * 3,
-                                 (tile * TV + tid) * 12, op);
-            if (plan.aabb) {
-                float a0 = op[0], a1 = op[1], a2 = op[2], b0 = op[0], b1 = op[1], b2 = op[2];
-                wave_minmax6(a0, a1, a2, b0, b1, b2);
-                if ((tid & 63) == 63) {
-                    float* dst = part[wave];
-                    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = b0; dst[4] = b1; dst[5] = b2;
+                float d[9];
+                const bool has = morph_load(rig.mblock + mp.data_off + (mp.dense ? wave * kMorphWaveFloats : 0u), mp.dense != 0, tid, d);
+#pragma unroll
+                for (uint32_t b = 0; b < kFixBatch; ++b) {
+                    if (!((act[b] >> q) & 1ull)) continue;  // wave-uniform
+                    const float mw = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mwq[b]), q));
+                    if (has) morph_add<EXACT>(mw, d, p[b], n[b], t[b]);
                 }
+            }
+            if (pend - pbeg > 64) {  // pairs beyond the first 64 (rare): per instance, still ascending
+#pragma unroll
+                for (uint32_t b = 0; b < kFixBatch; ++b) {
+                    if (b >= nb) continue;
+                    const float* mwg = cr.mw + (size_t)inst[b] * M;
+                    for (uint32_t q = pbeg + 64; q < pend; ++q) {
+                        const MorphPair mp = rig.pairs[q];
+                        const float mw = mwg[mp.target];
+                        if (mw == 0.0f || !((mp.wave_mask >> wave) & 1u)) continue;  // wave-uniform; adds exactly 0
+                        const bool dense = mp.dense != 0;
+                        morph_pair<EXACT>(rig.mblock + mp.data_off + (dense ? wave * kMorphWaveFloats : 0u), dense, tid, mw, p[b], n[b], t[b]);
+                    }
+                }
+            }
+            // the weight registers are free: the next batch's weights
+#pragma unroll
+            for (uint32_t b = 0; b < kFixBatch; ++b)
+                mwq[b] = (b < nnb && lane < np64) ? cr.mw[(size_t)inst_n[b] * M + pairs_l[lane].target] : 0.0f;
+#pragma unroll
+            for (uint32_t b = 0; b < kFixBatch; ++b) {
+                if (b >= nb) continue;  // block-uniform
+                // stage this instance's palette rows; the buffers alternate, so the one barrier below
+                // also separates the previous entry's reads of this buffer from these writes
+                f4* ps = pal_s[flip];
+                flip ^= 1u;
+                if (tid < npieces) ps[tid] = piece[b];
+                if (b < nnb && tid < npieces) piece[b] = pal_g[(size_t)inst_n[b] * rig.J * 6 + joff];  // and the next batch's piece
                 lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
-                if (tid < 6) {
-                    float r = part[0][tid];
-                    for (int q = 1; q < 4; ++q) r = tid < 3 ? fminf(r, part[q][tid]) : fmaxf(r, part[q][tid]);
-                    cr.aabb_part[((size_t)inst * rig.T + tile) * 6 + tid] = r;
+                float op[3];
+                skin_store<EXACT, NEXACT, K, SKIP>(LdsPal{ps}, w, li, ninf, p[b], n[b], t[b], normalize, valid && !(SKINRT_FIX_ABLATE & 2), out,
+                                                   (size_t)inst[b] * rig.V * 3, (tile * TV + tid) * 12, op);
+                if (plan.aabb) {
+                    float a0 = op[0], a1 = op[1], a2 = op[2], c0 = op[0], c1 = op[1], c2 = op[2];
+                    wave_minmax6(a0, a1, a2, c0, c1, c2);
+                    if ((tid & 63) == 63) {
+                        float* dst = part[wave];
+                        dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = c0; dst[4] = c1; dst[5] = c2;
+                    }
+                    lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
+                    if (tid < 6) {
+                        float r = part[0][tid];
+                        for (int q = 1; q < 4; ++q) r = tid < 3 ? fminf(r, part[q][tid]) : fmaxf(r, part[q][tid]);
+                        cr.aabb_part[((size_t)inst[b] * rig.T + tile) * 6 + tid] = r;
+                    }
+                    // part[] is next written after the next entry's first barrier
                 }
-                // part[] is next written after the next entry's first barrier
+            }
+            // pieces of next-batch entries past this batch's end (nnb > nb: a short batch before a full one) are still to fetch
+#pragma unroll
+            for (uint32_t b = 0; b < kFixBatch; ++b) {
+                if (b >= nb && b < nnb && tid < npieces) piece[b] = pal_g[(size_t)inst_n[b] * rig.J * 6 + joff];
+                inst[b] = inst_n[b];
             }
         }
+        ents = ents_next;
     }
 }
 
@@ -1589,7 +1668,7 @@ uint32_t skin_build_flags() {
     f |= SKINRT_BUILD_STAMPS;
 #endif
     if (SKINRT_RANGE2 != 80 || SKINRT_MORPH_SLOTS != 2 || SKINRT_INFLIGHT != 2 || SKINRT_BLOCKS_K1 != 5 || SKINRT_ORDER_ROT != 23u ||
-        SKINRT_STORE_POLICY != 1 || sizeof(SKINRT_PAL_MOD) != 1 || SKINRT_SPARSE_SLOTS != 1)
+        SKINRT_STORE_POLICY != 1 || sizeof(SKINRT_PAL_MOD) != 1 || SKINRT_SPARSE_SLOTS != 1 || SKINRT_FIX_BATCH != 0)
         f |= SKINRT_BUILD_TUNING;
     return f;
 }
