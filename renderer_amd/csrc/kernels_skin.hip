@@ -931,21 +931,24 @@ __global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdD
 #define SKINRT_FIX_ABLATE 0
 #endif
 constexpr uint32_t kFixChunk = 8;
-// instances of a chunk morphed together (kFixChunk is a multiple): 0 = the product's choice per weight-set count — 4 for
+// instances of a chunk morphed together (kFixChunk is a multiple): 0 = the product's choice per rig (launch_skin) — 4 for
 // K = 1 (119 VGPRs: fits beside k_skin2's five blocks), 2 for K = 2 (4 needs 131-134 VGPRs and no longer fits beside
 // k_skin2's four: C5 +8 %; 2 against 1: C5 -1.7 %, 10.49 / 10.47 / 10.46 -> 10.30 / 10.33 / 10.18).  C3 does not care
 // (4.21-4.24 ms with 1, 2 or 4); a face under tracking (tools/exp_face.py: 52 targets all active) 6.90 -> 5.58 ms with 4.
+// K = 1 rigs that hand whole tiles over (kind 3: every instance listed, most of them with no active pair at all) take 2:
+// there the lists are long, k_skin_fix runs as long as k_skin2, and the batch's 36 extra registers only cost —
+// C3's avatar cut into three skins (bench.py --multi-skin): k_skin_fix 4.80 -> 4.42 ms, the stage 4.64 -> 4.33.
 #ifndef SKINRT_FIX_BATCH
 #define SKINRT_FIX_BATCH 0
 #endif
 constexpr uint32_t kFixLdsBytes = 2 * 128 * 16 + 4 * 6 * 4 + 32 + 64 * sizeof(MorphPair);  // of the block's dynamic LDS
 // fb = this block's index among the kernel's `fix_blocks` blocks (a multiple of 8 * ceil(T / 8))
-template <int AR, int K, bool SKIP>
+template <int AR, int K, bool SKIP, int BATCH>
 __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, float4* smem, uint32_t fb, uint32_t fix_blocks) {
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
     constexpr bool EXACT = AR != 0, NEXACT = AR == 1;  // AR 2: positions contraction-free, normals / tangents fused
-    constexpr uint32_t kFixBatch = SKINRT_FIX_BATCH ? SKINRT_FIX_BATCH : (K == 1 ? 4u : 2u);
+    constexpr uint32_t kFixBatch = SKINRT_FIX_BATCH ? SKINRT_FIX_BATCH : (uint32_t)BATCH;
     static_assert(kFixChunk % kFixBatch == 0, "a chunk is a whole number of batches");
     f4 (*pal_s)[128] = reinterpret_cast<f4 (*)[128]>(smem);                            // [2][128]
     float (*part)[6] = reinterpret_cast<float (*)[6]>(pal_s + 2);                        // [4][6] (+ 32 B pad)
@@ -1481,10 +1484,10 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
 // The fix role's kernel.  (Tried: the role inside the k_skin2 launch, its block groups dealt out between the
 // self-staging groups.  Slower — 5.7-6.0 ms against 4.7 on C3: a launch has ONE LDS size, so every fix block takes
 // one of the CU's five 31 KiB block slots from k_skin2; as a kernel of its own it fits into what k_skin2 leaves free.)
-template <int AR, int K, bool SKIP>
+template <int AR, int K, bool SKIP, int BATCH>
 __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
-    fix_role<AR, K, SKIP>(rig, cr, plan, smem, blockIdx.x, gridDim.x);
+    fix_role<AR, K, SKIP, BATCH>(rig, cr, plan, smem, blockIdx.x, gridDim.x);
 }
 
 // a14: bounds of one instance = min/max over its tiles' partial bounds (order-independent, exact).
@@ -1596,16 +1599,19 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
             // enough lanes that the longest list is a few chunks per block; blocks past a list's end leave at once
             const uint32_t lanes = std::min((cr.I + kFixChunk - 1) / kFixChunk, std::max(1u, conc.fix_blocks / rig.T));
             const dim3 fgrid(8u * ((rig.T + 7) / 8) * lanes), fblock(256);
-#define SKINRT_LAUNCHF(EX, KK, SK) hipLaunchKernelGGL((k_skin_fix<EX, KK, SK>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan)
-#define SKINRT_LAUNCHFA(KK, SK)                                                            \
+#define SKINRT_LAUNCHF(EX, KK, SK, BB) hipLaunchKernelGGL((k_skin_fix<EX, KK, SK, BB>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan)
+#define SKINRT_LAUNCHFA(KK, SK, BB)                                                        \
     do {                                                                                   \
-        if (plan.exact == 1) SKINRT_LAUNCHF(1, KK, SK);                                    \
-        else if (plan.exact == 2) SKINRT_LAUNCHF(2, KK, SK);                               \
-        else SKINRT_LAUNCHF(0, KK, SK);                                                    \
+        if (plan.exact == 1) SKINRT_LAUNCHF(1, KK, SK, BB);                                \
+        else if (plan.exact == 2) SKINRT_LAUNCHF(2, KK, SK, BB);                           \
+        else SKINRT_LAUNCHF(0, KK, SK, BB);                                                \
     } while (0)
-            if (rig.K == 1) SKINRT_LAUNCHFA(1, false);
-            else if (rig.skip_sets) SKINRT_LAUNCHFA(2, true);
-            else SKINRT_LAUNCHFA(2, false);
+            // instances morphed per read of a pair's deltas (see SKINRT_FIX_BATCH): 4 for one weight set, unless whole
+            // tiles are handed over (kind 3) — then, and for two weight sets, 2
+            if (rig.K == 1 && (plan.kinds & 8u)) SKINRT_LAUNCHFA(1, false, 2);
+            else if (rig.K == 1) SKINRT_LAUNCHFA(1, false, 4);
+            else if (rig.skip_sets) SKINRT_LAUNCHFA(2, true, 2);
+            else SKINRT_LAUNCHFA(2, false, 2);
 #undef SKINRT_LAUNCHFA
 #undef SKINRT_LAUNCHF
             if ((fe = hipGetLastError()) != hipSuccess) return fe;
