@@ -320,7 +320,7 @@ SKINRT_API const char* skinrt_last_error(void);
  * streams / blocks / launch orders for measurements (tools/, profiles/) and never change a result.  Unset = the
  * product's choice, which is what every number in DESIGN.md is measured with.
  *   SKINRT_FIX_STREAM  0: the skin stage's kernels one after the other on the ctx stream (default 1: k_skin_fix beside k_skin2)
- *   SKINRT_FIX_PRIO    priority of that side stream: -1 most urgent, 0 default, 1 least urgent (default)
+ *   SKINRT_FIX_PRIO    priority of that side stream: -1 most urgent, 0 default (default), 1 least urgent
  *   SKINRT_FIX_ORDER   1: enqueue k_skin2 before k_skin_fix (default 0)
  *   SKINRT_FIX_BLOCKS  about this many k_skin_fix blocks (default 32768)
  *   SKINRT_POSE_PRE    0: sample channels inside the pose kernels, no node-major scratch (default 1)

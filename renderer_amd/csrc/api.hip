@@ -56,7 +56,7 @@ struct DevBuf {
 // in include/skinrt.h; none of them changes a result.
 struct EnvKnobs {
     int fix_stream = 1;          // SKINRT_FIX_STREAM=0: the skin stage's kernels one after the other
-    int fix_prio = 1;            // SKINRT_FIX_PRIO: -1 urgent, 0 default, 1 least urgent side stream
+    int fix_prio = 0;            // SKINRT_FIX_PRIO: -1 urgent, 0 default, 1 least urgent side stream
     uint32_t fix_order = 0;      // SKINRT_FIX_ORDER=1: enqueue k_skin2 before k_skin_fix
     uint32_t fix_blocks = 32768; // SKINRT_FIX_BLOCKS: about this many k_skin_fix blocks
     int pose_pre = 1;            // SKINRT_POSE_PRE=0: sample channels inside the pose kernels (no local_t scratch)
@@ -71,7 +71,7 @@ struct EnvKnobs {
     }
     void read() {
         fix_stream = num("SKINRT_FIX_STREAM", 1);
-        fix_prio = num("SKINRT_FIX_PRIO", 1);
+        fix_prio = num("SKINRT_FIX_PRIO", 0);
         fix_order = (uint32_t)std::max(0, num("SKINRT_FIX_ORDER", 0));
         fix_blocks = (uint32_t)std::max(1, num("SKINRT_FIX_BLOCKS", 32768));
         pose_pre = num("SKINRT_POSE_PRE", 1);
@@ -294,7 +294,8 @@ int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx) {
         if (ctx->env.fix_stream != 0) {
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent (largest number)
-            const int want = ctx->env.fix_prio;  // -1 urgent, 0 default, 1 least urgent (default: it only fills what k_skin2 leaves free)
+            const int want = ctx->env.fix_prio;  // -1 urgent, 0 default (the product), 1 least urgent — see profiles/r03_ubench.txt: k_skin_fix ends 0.18 ms after
+                                                 // k_skin2 on C3 at the least urgent priority; at the default one the two end closer together
             e = hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, want < 0 ? hi : (want > 0 ? lo : (lo + hi) / 2));
             if (e != hipSuccess) {
                 (void)hipStreamDestroy(ctx->stream);
