@@ -1,4 +1,4 @@
-//! Raw bindings of `include/skinrt.h` (ABI version 6), field for field and function for function.
+//! Raw bindings of `include/skinrt.h` (ABI version 7), field for field and function for function.
 //!
 //! `tests/test_rust_bindings.py` (CPU) parses the `#[repr(C)]` structs and the `extern "C"` block below, lays
 //! the structs out by the C rules and compares sizes, field offsets and the function list with what `gcc`
@@ -16,7 +16,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const SKINRT_ABI_VERSION: c_int = 6;
+pub const SKINRT_ABI_VERSION: c_int = 7;
 
 pub const SKINRT_OK: c_int = 0;
 pub const SKINRT_E_INVALID: c_int = -1;
@@ -51,6 +51,8 @@ pub const SKINRT_BUILD_TUNING: u32 = 8;
 pub const SKINRT_TANGENT_NOALLOC_MAX_VERTICES: u32 = 262_144;
 pub const SKINRT_TANGENT_NOALLOC_MAX_INDICES: u32 = 1_572_864;
 pub const SKINRT_TANGENT_MAX_VALENCE: u32 = 49_152;
+pub const SKINRT_OUTPUT_NORMALS: u32 = 0;
+pub const SKINRT_OUTPUT_TANGENTS: u32 = 1;
 
 #[repr(C)]
 pub struct skinrt_ctx {
@@ -66,6 +68,10 @@ pub struct skinrt_crowd {
 }
 #[repr(C)]
 pub struct skinrt_node {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct skinrt_topology {
     _private: [u8; 0],
 }
 
@@ -285,6 +291,10 @@ extern "C" {
                                     index_count: u32, out: *mut f32, out_device_ms: *mut f32) -> c_int;
     pub fn skinrt_calculate_tangent_noalloc(ctx: *mut skinrt_ctx, mode: u32, dev_positions: *const f32, vertex_count: u32,
                                             dev_indices: *const u32, index_count: u32, dev_out: *mut f32) -> c_int;
+    pub fn skinrt_create_topology(ctx: *mut skinrt_ctx, vertex_count: u32, indices: *const u32, index_count: u32,
+                                  out_topology: *mut *mut skinrt_topology) -> c_int;
+    pub fn skinrt_destroy_topology(topology: *mut skinrt_topology) -> c_int;
+    pub fn skinrt_recompute_normals(crowd: *mut skinrt_crowd, topology: *mut skinrt_topology, first: u32, count: u32, output: u32) -> c_int;
 
     pub fn skinrt_node_create(config: *const skinrt_config, devices: *const i32, device_count: u32, desc: *const skinrt_rig_desc,
                               instances: u32, out_node: *mut *mut skinrt_node) -> c_int;

@@ -255,6 +255,12 @@ impl Crowd<'_> {
                                                        dev_dst: *mut u8) -> Result<(), Error> {
         check(sys::skinrt_export_interleaved_section_device(self.raw, section, first, count, sys::SKINRT_LAYOUT_TEXTURE_SKIN, dev_tex_coords, dev_dst.cast()))
     }
+    /// `calculate_tangent(TriangleList, positions[i], indices)` (renderer-asset/src/tangent.rs:15-58) of instances
+    /// `first .. first + count` from the positions the last `evaluate` produced, written over their normals
+    /// (`SKINRT_OUTPUT_NORMALS`) or tangents (`SKINRT_OUTPUT_TANGENTS`); enqueued behind the evaluate, no host wait.
+    pub fn recompute_normals(&mut self, topology: &Topology<'_>, first: u32, count: u32, output: u32) -> Result<(), Error> {
+        check(unsafe { sys::skinrt_recompute_normals(self.raw, topology.raw, first, count, output) })
+    }
     pub fn instances(&self) -> u32 { self.instances }
     pub fn joints(&self) -> u32 { self.joints }
     pub fn vertices(&self) -> u32 { self.vertices }
@@ -263,6 +269,31 @@ impl Crowd<'_> {
 impl Drop for Crowd<'_> {
     fn drop(&mut self) {
         unsafe { sys::skinrt_destroy_crowd(self.raw) };
+    }
+}
+
+/// A mesh's triangle list prepared once for per-frame normals (`skinrt_create_topology`): `indices` as the loader
+/// holds them (`PrimitiveAsset.indices`, primitive.rs:47), offset by the section's first vertex when the rig has several
+/// mesh nodes; `None` = every three vertices form a triangle, as `calculate_tangent` treats a primitive without indices.
+pub struct Topology<'c> {
+    raw: *mut sys::skinrt_topology,
+    _ctx: PhantomData<&'c ()>,
+}
+
+impl<'c> Topology<'c> {
+    pub fn new(ctx: &'c Context, vertex_count: u32, indices: Option<&[u32]>) -> Result<Self, Error> {
+        let mut raw = ptr::null_mut();
+        check(unsafe {
+            sys::skinrt_create_topology(ctx.raw, vertex_count, indices.map(|i| i.as_ptr()).unwrap_or(ptr::null()),
+                                        indices.map(|i| i.len() as u32).unwrap_or(0), &mut raw)
+        })?;
+        Ok(Topology { raw, _ctx: PhantomData })
+    }
+}
+
+impl Drop for Topology<'_> {
+    fn drop(&mut self) {
+        unsafe { sys::skinrt_destroy_topology(self.raw) };
     }
 }
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SKINRT_ABI_VERSION 6
+#define SKINRT_ABI_VERSION 7
 #define SKINRT_API __attribute__((visibility("default")))
 
 /* ---- error codes ---------------------------------------------------------------- */
@@ -523,6 +523,30 @@ SKINRT_API int skinrt_calculate_tangent(skinrt_ctx* ctx, uint32_t mode, const fl
 #define SKINRT_TANGENT_NOALLOC_MAX_INDICES 1572864u
 SKINRT_API int skinrt_calculate_tangent_noalloc(skinrt_ctx* ctx, uint32_t mode, const float* dev_positions, uint32_t vertex_count,
                                      const uint32_t* dev_indices, uint32_t index_count, float* dev_out);
+
+/* ---- per-frame normals from the DEFORMED positions ("per-frame normal recompute after morphing") ----
+ * The reference generates normals / "tangents" once, at load, from the bind-pose positions (calculate_tangent,
+ * tangent.rs:15-58; loader/gltf/mod.rs:1086-1089) and only transforms them afterwards; under strong morphs (a face) or
+ * where the asset had no normals at all, a renderer wants the same generator run on what the frame produced.  A topology
+ * is a mesh's triangle list prepared for that, once: vertex_count = the RIG's vertex count (all sections; a section's
+ * indices are offset by its first vertex, skinrt_rig_section_layout), indices host [index_count] (whole triangles are
+ * used: index_count / 3 of them, tangent.rs:29) or NULL (vertices 3f, 3f+1, 3f+2 form triangle f).
+ * An index >= vertex_count is SKINRT_E_INVALID, a vertex named by more than SKINRT_TANGENT_MAX_VALENCE corners
+ * SKINRT_E_LIMIT.  The call blocks until the tables are built (the index list is borrowed for the call only). */
+typedef struct skinrt_topology skinrt_topology;
+SKINRT_API int skinrt_create_topology(skinrt_ctx* ctx, uint32_t vertex_count, const uint32_t* indices, uint32_t index_count,
+                                      skinrt_topology** out_topology);
+SKINRT_API int skinrt_destroy_topology(skinrt_topology* topology);  /* waits for the ctx stream; NULL is a no-op */
+/* For instances [first, first + count): output[i][v] = calculate_tangent(TriangleList, positions[i], indices)[v] — bit for
+ * bit what skinrt_calculate_tangent returns for that instance's skinned positions (vertices no triangle touches and
+ * degenerate sums give NaN, as the reference) — written over the instance's normals (SKINRT_OUTPUT_NORMALS) or tangents
+ * (SKINRT_OUTPUT_TANGENTS; the reference's loader uses the same vector for both when an asset has neither,
+ * loader/gltf/mod.rs:1086-1089).  Enqueued on the ctx stream behind the evaluate that produced the positions; does not
+ * synchronise.  One kernel, thread = (instance, vertex): the face normals a vertex needs are recomputed from the
+ * instance's positions in the reference's order, no per-instance face table exists. */
+#define SKINRT_OUTPUT_NORMALS 0u
+#define SKINRT_OUTPUT_TANGENTS 1u
+SKINRT_API int skinrt_recompute_normals(skinrt_crowd* crowd, skinrt_topology* topology, uint32_t first, uint32_t count, uint32_t output);
 
 /* ---- one crowd over several GPUs of this process ------------------------------------
  * No reference counterpart (the reference renders on one adapter).  A node holds one ctx, one copy of the rig and

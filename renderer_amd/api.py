@@ -39,6 +39,7 @@ EXPORTS = [
     "skinrt_export_skin_uniform_of", "skinrt_export_interleaved_section", "skinrt_export_instance_uniform",
     "skinrt_export_skin_uniform_of_device", "skinrt_export_interleaved_section_device", "skinrt_export_instance_uniform_device",
     "skinrt_export_skin_storage_device",
+    "skinrt_create_topology", "skinrt_destroy_topology", "skinrt_recompute_normals",
     "skinrt_node_create", "skinrt_node_destroy", "skinrt_node_shard_count", "skinrt_node_get_shard", "skinrt_node_set_clocks",
     "skinrt_node_set_morph_weights", "skinrt_node_set_root_transforms", "skinrt_node_evaluate", "skinrt_node_synchronize",
     "skinrt_node_download_aabbs",
@@ -105,6 +106,9 @@ def load_library() -> C.CDLL:
         "skinrt_shard_range": [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
         "skinrt_calculate_tangent": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(C.c_float)],
         "skinrt_calculate_tangent_noalloc": [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp],
+        "skinrt_create_topology": [vp, C.c_uint32, vp, C.c_uint32, C.POINTER(vp)],
+        "skinrt_destroy_topology": [vp],
+        "skinrt_recompute_normals": [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32],
         "skinrt_node_create": [C.POINTER(Config), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(RigDesc), C.c_uint32, C.POINTER(vp)],
         "skinrt_node_destroy": [vp],
         "skinrt_node_shard_count": [vp, C.POINTER(C.c_uint32)],
@@ -250,6 +254,28 @@ class Rig:
             self.handle = C.c_void_p()
 
 
+class Topology:
+    """A mesh's triangle list prepared once for per-frame normals (skinrt_create_topology)."""
+
+    def __init__(self, ctx: Context, vertex_count: int, indices=None):
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        idx = None if indices is None else np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        _check(ctx.lib.skinrt_create_topology(ctx.handle, int(vertex_count), None if idx is None else idx.ctypes.data_as(C.c_void_p),
+                                              0 if idx is None else idx.shape[0], C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.skinrt_destroy_topology(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 class Crowd:
     def __init__(self, ctx: Context, rig: Rig, instances: int):
         self.ctx, self.rig, self.instances = ctx, rig, int(instances)
@@ -324,6 +350,14 @@ class Crowd:
         ms = (C.c_float * 4)()
         _check(self.ctx.lib.skinrt_last_stage_ms(self.handle, C.byref(ms)))
         return tuple(float(x) for x in ms)
+
+    def recompute_normals(self, topology: "Topology", first: int = 0, count: Optional[int] = None, output: int = 0, sync: bool = False):
+        """skinrt_recompute_normals: calculate_tangent (tangent.rs:15-58) of every instance's skinned positions, written
+        over its normals (output 0) or tangents (1); stream-ordered behind the evaluate."""
+        n = self.instances - first if count is None else count
+        _check(self.ctx.lib.skinrt_recompute_normals(self.handle, topology.handle, first, n, output))
+        if sync:
+            self.ctx.synchronize()
 
     # outputs ---------------------------------------------------------------------------------
     def _dev(self, name: str) -> Tuple[int, int]:

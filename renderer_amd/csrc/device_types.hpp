@@ -139,6 +139,11 @@ hipError_t tangent_static_area(int device, void** ptr, size_t* bytes);   // the 
 hipError_t tangent_static_use(int device, hipStream_t s, hipError_t (*launch)(void*), void* arg);
 hipError_t launch_tangents(const float* pos, const uint32_t* indices, uint32_t vertices, uint32_t corners, void* work, size_t work_bytes,
                            float* out, hipStream_t s);
+// the corner buckets of a mesh, sorted once (inside `work`), and calculate_tangent per (instance, vertex) of a crowd from them
+hipError_t launch_topology(const uint32_t* indices, uint32_t vertices, uint32_t corners, void* work, size_t work_bytes,
+                           const uint32_t** out_start, const uint32_t** out_adj, hipStream_t s);
+hipError_t launch_crowd_normals(const float* pos_all, const uint32_t* indices, const uint32_t* start, const uint32_t* adj,
+                                uint32_t vertices, uint32_t first, uint32_t count, float* out_all, hipStream_t s);
 // placement.hip: the three output arrays, steered over the HBM's regions and measured
 hipError_t allocate_outputs(int device, size_t bytes_each, uint32_t V, uint32_t I, uint32_t mode, uint32_t max_filler_gib, hipStream_t s,
                             void** pos, void** nrm, void** tan, skinrt_placement_info* info);

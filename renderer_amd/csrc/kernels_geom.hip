@@ -9,6 +9,11 @@
 // order in which the sequential loop reached it — and adds the face normals in that order.  The
 // result is bit-equal to the sequential loop.  Compiled with -ffp-contract=off (glam's scalar Vec3
 // does separate multiplies and adds).
+//
+// The same sum PER FRAME on a crowd's deformed positions (the second half of that row: "per-frame normal recompute
+// after morphing"): a topology object keeps the mesh's corner buckets, sorted once; k_crowd_normals then evaluates
+// calculate_tangent for every (instance, vertex) from that instance's skinned positions, face normals recomputed where
+// they are used (no [instances][faces] scratch), in the same order with the same operations.
 #include <hip/hip_runtime.h>
 
 #include <mutex>
@@ -29,17 +34,22 @@ __device__ __forceinline__ bool face_valid(const uint32_t* __restrict__ indices,
 }
 
 // unit normal of face f: normalize((p2 - p1) x (p0 - p1)), glam operation order (tangent.rs:32-41)
-__global__ __launch_bounds__(256) void k_face_normals(const float* __restrict__ pos, const uint32_t* __restrict__ indices,
-                                                      uint32_t faces, uint32_t vertices, float* __restrict__ fn) {
-    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= faces || !face_valid(indices, f, vertices)) return;
+__device__ __forceinline__ void face_unit_normal(const float* __restrict__ pos, const uint32_t* __restrict__ indices, uint32_t f, float (&n)[3]) {
     const uint32_t i0 = corner_vertex(indices, 3 * f), i1 = corner_vertex(indices, 3 * f + 1), i2 = corner_vertex(indices, 3 * f + 2);
     const float* p0 = pos + (size_t)i0 * 3; const float* p1 = pos + (size_t)i1 * 3; const float* p2 = pos + (size_t)i2 * 3;
     const float a[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
     const float b[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
     const float c[3] = {a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1]};
     const float r = 1.0f / sqrtf((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
-    fn[(size_t)f * 3 + 0] = c[0] * r; fn[(size_t)f * 3 + 1] = c[1] * r; fn[(size_t)f * 3 + 2] = c[2] * r;
+    n[0] = c[0] * r; n[1] = c[1] * r; n[2] = c[2] * r;
+}
+__global__ __launch_bounds__(256) void k_face_normals(const float* __restrict__ pos, const uint32_t* __restrict__ indices,
+                                                      uint32_t faces, uint32_t vertices, float* __restrict__ fn) {
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= faces || !face_valid(indices, f, vertices)) return;
+    float n[3];
+    face_unit_normal(pos, indices, f, n);
+    fn[(size_t)f * 3 + 0] = n[0]; fn[(size_t)f * 3 + 1] = n[1]; fn[(size_t)f * 3 + 2] = n[2];
 }
 
 __global__ __launch_bounds__(256) void k_corner_count(const uint32_t* __restrict__ indices, uint32_t corners, uint32_t vertices,
@@ -76,16 +86,8 @@ __device__ void sift_down(uint32_t* a, uint32_t root, uint32_t n) {
     }
     a[root] = key;
 }
-__global__ __launch_bounds__(256) void k_vertex_sum(uint32_t vertices, const uint32_t* __restrict__ start, uint32_t* __restrict__ adj,
-                                                    const float* __restrict__ fn, float* __restrict__ out) {
-    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= vertices) return;
-    const uint32_t b = start[v], e = start[v + 1];
-    if (e - b > SKINRT_TANGENT_MAX_VALENCE) {
-        const float nan = __builtin_nanf("");
-        out[(size_t)v * 3 + 0] = nan; out[(size_t)v * 3 + 1] = nan; out[(size_t)v * 3 + 2] = nan;
-        return;
-    }
+// corner ids adj[b .. e) ascending, in place
+__device__ __forceinline__ void sort_corners(uint32_t* adj, uint32_t b, uint32_t e) {
     if (e - b <= kInsertionMax) {
         for (uint32_t i = b + 1; i < e; ++i) {
             const uint32_t key = adj[i];
@@ -104,6 +106,18 @@ __global__ __launch_bounds__(256) void k_vertex_sum(uint32_t vertices, const uin
             sift_down(a, 0, m);
         }
     }
+}
+__global__ __launch_bounds__(256) void k_vertex_sum(uint32_t vertices, const uint32_t* __restrict__ start, uint32_t* __restrict__ adj,
+                                                    const float* __restrict__ fn, float* __restrict__ out) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= vertices) return;
+    const uint32_t b = start[v], e = start[v + 1];
+    if (e - b > SKINRT_TANGENT_MAX_VALENCE) {
+        const float nan = __builtin_nanf("");
+        out[(size_t)v * 3 + 0] = nan; out[(size_t)v * 3 + 1] = nan; out[(size_t)v * 3 + 2] = nan;
+        return;
+    }
+    sort_corners(adj, b, e);
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
     for (uint32_t i = b; i < e; ++i) {
         const float* n = fn + (size_t)(adj[i] / 3) * 3;
@@ -111,6 +125,42 @@ __global__ __launch_bounds__(256) void k_vertex_sum(uint32_t vertices, const uin
     }
     const float r = 1.0f / sqrtf((s0 * s0 + s1 * s1) + s2 * s2);
     out[(size_t)v * 3 + 0] = s0 * r; out[(size_t)v * 3 + 1] = s1 * r; out[(size_t)v * 3 + 2] = s2 * r;
+}
+
+// topology: every vertex's corner list sorted once (k_vertex_sum sorts on every call because its work area is per call)
+__global__ __launch_bounds__(256) void k_sort_corners(uint32_t vertices, const uint32_t* __restrict__ start, uint32_t* __restrict__ adj) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= vertices) return;
+    const uint32_t b = start[v], e = start[v + 1];
+    if (e - b <= SKINRT_TANGENT_MAX_VALENCE) sort_corners(adj, b, e);
+}
+
+// calculate_tangent per (instance, vertex) of a crowd: thread = vertex v of instance first + blockIdx.y.  pos_all / out_all:
+// [instances][vertices][3].  The face normals a vertex needs are recomputed from the instance's positions (each is
+// computed once per corner that uses it: three times per triangle, the same bits every time) — an instance's positions
+// are L2-resident for the block row that walks it, and no [instances][faces] table has to exist.
+__global__ __launch_bounds__(256) void k_crowd_normals(const float* __restrict__ pos_all, const uint32_t* __restrict__ indices,
+                                                       const uint32_t* __restrict__ start, const uint32_t* __restrict__ adj,
+                                                       uint32_t vertices, uint32_t first, float* __restrict__ out_all) {
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= vertices) return;
+    const size_t row = (size_t)(first + blockIdx.y) * vertices * 3;
+    const float* pos = pos_all + row;
+    float* out = out_all + row + (size_t)v * 3;
+    const uint32_t b = start[v], e = start[v + 1];
+    if (e - b > SKINRT_TANGENT_MAX_VALENCE) {
+        const float nan = __builtin_nanf("");
+        out[0] = nan; out[1] = nan; out[2] = nan;
+        return;
+    }
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    for (uint32_t i = b; i < e; ++i) {
+        float n[3];
+        face_unit_normal(pos, indices, adj[i] / 3, n);
+        s0 += n[0]; s1 += n[1]; s2 += n[2];
+    }
+    const float r = 1.0f / sqrtf((s0 * s0 + s1 * s1) + s2 * s2);
+    out[0] = s0 * r; out[1] = s1 * r; out[2] = s2 * r;
 }
 
 // Exclusive prefix sum of n counters (integers: exact in any order).  Three small kernels instead of a
@@ -254,6 +304,45 @@ hipError_t launch_tangents(const float* pos, const uint32_t* indices, uint32_t v
     hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, s, start, n, chunk_sum);
     if (corners) hipLaunchKernelGGL(k_corner_fill, dim3((corners + 255) / 256), dim3(256), 0, s, indices, corners, vertices, start, cursor, adj);
     hipLaunchKernelGGL(k_vertex_sum, dim3((vertices + 255) / 256), dim3(256), 0, s, vertices, start, adj, fn, out);
+    return hipGetLastError();
+}
+
+// The corner buckets of a mesh, built once: start[V + 1] and adj[corners] (each vertex's corner ids ascending) inside
+// `work` (tangent_work_bytes(V, corners) bytes, 256-byte aligned, kept by the caller for as long as the tables are used).
+hipError_t launch_topology(const uint32_t* indices, uint32_t vertices, uint32_t corners, void* work, size_t work_bytes,
+                           const uint32_t** out_start, const uint32_t** out_adj, hipStream_t s) {
+    if (vertices == 0) return hipErrorInvalidValue;
+    if (tangent_work_bytes(vertices, corners) > work_bytes || (reinterpret_cast<uintptr_t>(work) & 255u)) return hipErrorInvalidValue;
+    const uint32_t n = vertices + 1, chunks = (n + kScanChunk - 1) / kScanChunk;
+    char* w = static_cast<char*>(work);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(w);              w += align256((size_t)n * 4);
+    uint32_t* start = reinterpret_cast<uint32_t*>(w);            w += align256((size_t)n * 4);
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(w);           w += align256((size_t)n * 4);
+    uint32_t* adj = reinterpret_cast<uint32_t*>(w);              w += align256((size_t)corners * 4);
+    w += align256((size_t)corners * 4);  // (the face-normal table of launch_tangents: unused here)
+    uint32_t* chunk_sum = reinterpret_cast<uint32_t*>(w);
+    hipError_t e = hipMemsetAsync(cnt, 0, 3 * align256((size_t)n * 4), s);
+    if (e != hipSuccess) return e;
+    if (corners) hipLaunchKernelGGL(k_corner_count, dim3((corners + 255) / 256), dim3(256), 0, s, indices, corners, vertices, cnt);
+    hipLaunchKernelGGL(k_scan_chunks, dim3(chunks), dim3(256), 0, s, cnt, n, start, chunk_sum);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, s, chunk_sum, chunks);
+    hipLaunchKernelGGL(k_scan_add, dim3((n + 255) / 256), dim3(256), 0, s, start, n, chunk_sum);
+    if (corners) hipLaunchKernelGGL(k_corner_fill, dim3((corners + 255) / 256), dim3(256), 0, s, indices, corners, vertices, start, cursor, adj);
+    hipLaunchKernelGGL(k_sort_corners, dim3((vertices + 255) / 256), dim3(256), 0, s, vertices, start, adj);
+    *out_start = start;
+    *out_adj = adj;
+    return hipGetLastError();
+}
+
+// calculate_tangent of instances [first, first + count) of a crowd from their positions; pos_all / out_all [I][V][3]
+hipError_t launch_crowd_normals(const float* pos_all, const uint32_t* indices, const uint32_t* start, const uint32_t* adj,
+                                uint32_t vertices, uint32_t first, uint32_t count, float* out_all, hipStream_t s) {
+    if (vertices == 0) return hipSuccess;
+    for (uint32_t done = 0; done < count;) {  // gridDim.y holds at most 65,535 instances
+        const uint32_t n = count - done < 65535u ? count - done : 65535u;
+        hipLaunchKernelGGL(k_crowd_normals, dim3((vertices + 255) / 256, n), dim3(256), 0, s, pos_all, indices, start, adj, vertices, first + done, out_all);
+        done += n;
+    }
     return hipGetLastError();
 }
 
