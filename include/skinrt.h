@@ -542,8 +542,8 @@ SKINRT_API int skinrt_destroy_topology(skinrt_topology* topology);  /* waits for
  * degenerate sums give NaN, as the reference) — written over the instance's normals (SKINRT_OUTPUT_NORMALS) or tangents
  * (SKINRT_OUTPUT_TANGENTS; the reference's loader uses the same vector for both when an asset has neither,
  * loader/gltf/mod.rs:1086-1089).  Enqueued on the ctx stream behind the evaluate that produced the positions; does not
- * synchronise.  One kernel, thread = (instance, vertex): the face normals a vertex needs are recomputed from the
- * instance's positions in the reference's order, no per-instance face table exists. */
+ * synchronise.  One kernel, thread = one vertex of eight consecutive instances: the face normals a vertex needs are
+ * recomputed from each instance's positions in the reference's order, no per-instance face table exists. */
 #define SKINRT_OUTPUT_NORMALS 0u
 #define SKINRT_OUTPUT_TANGENTS 1u
 SKINRT_API int skinrt_recompute_normals(skinrt_crowd* crowd, skinrt_topology* topology, uint32_t first, uint32_t count, uint32_t output);

@@ -135,32 +135,56 @@ __global__ __launch_bounds__(256) void k_sort_corners(uint32_t vertices, const u
     if (e - b <= SKINRT_TANGENT_MAX_VALENCE) sort_corners(adj, b, e);
 }
 
-// calculate_tangent per (instance, vertex) of a crowd: thread = vertex v of instance first + blockIdx.y.  pos_all / out_all:
-// [instances][vertices][3].  The face normals a vertex needs are recomputed from the instance's positions (each is
-// computed once per corner that uses it: three times per triangle, the same bits every time) — an instance's positions
-// are L2-resident for the block row that walks it, and no [instances][faces] table has to exist.
+// calculate_tangent per (instance, vertex) of a crowd: thread = vertex v of NI consecutive instances (first + blockIdx.y * NI ...).
+// pos_all / out_all: [instances][vertices][3].  The face normals a vertex needs are recomputed from each instance's
+// positions (each is computed once per corner that uses it: three times per triangle, the same bits every time) — an
+// instance's positions are L2-resident for the block row that walks it, and no [instances][faces] table has to exist.
+// A corner's face and its three vertex indices are fetched once for the NI instances (they are the mesh's, not the
+// instance's): a third of the gathers of the one-instance form.  Per instance the additions keep the sequential order.
+constexpr uint32_t kNormalsInstances = 8;
 __global__ __launch_bounds__(256) void k_crowd_normals(const float* __restrict__ pos_all, const uint32_t* __restrict__ indices,
                                                        const uint32_t* __restrict__ start, const uint32_t* __restrict__ adj,
-                                                       uint32_t vertices, uint32_t first, float* __restrict__ out_all) {
+                                                       uint32_t vertices, uint32_t first, uint32_t count, float* __restrict__ out_all) {
+    constexpr uint32_t NI = kNormalsInstances;
     const uint32_t v = blockIdx.x * 256 + threadIdx.x;
     if (v >= vertices) return;
-    const size_t row = (size_t)(first + blockIdx.y) * vertices * 3;
-    const float* pos = pos_all + row;
-    float* out = out_all + row + (size_t)v * 3;
+    const uint32_t k0 = blockIdx.y * NI;                       // first of this thread's instances, relative to `first`
+    const uint32_t ni = count - k0 < NI ? count - k0 : NI;      // >= 1 by the grid's size
+    const size_t stride = (size_t)vertices * 3;
+    const float* pos0 = pos_all + (size_t)(first + k0) * stride;
+    float* out0 = out_all + (size_t)(first + k0) * stride + (size_t)v * 3;
     const uint32_t b = start[v], e = start[v + 1];
     if (e - b > SKINRT_TANGENT_MAX_VALENCE) {
         const float nan = __builtin_nanf("");
-        out[0] = nan; out[1] = nan; out[2] = nan;
+        for (uint32_t k = 0; k < ni; ++k) { float* o = out0 + k * stride; o[0] = nan; o[1] = nan; o[2] = nan; }
         return;
     }
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    float s[NI][3];
+#pragma unroll
+    for (uint32_t k = 0; k < NI; ++k) { s[k][0] = 0.0f; s[k][1] = 0.0f; s[k][2] = 0.0f; }
     for (uint32_t i = b; i < e; ++i) {
-        float n[3];
-        face_unit_normal(pos, indices, adj[i] / 3, n);
-        s0 += n[0]; s1 += n[1]; s2 += n[2];
+        const uint32_t f = adj[i] / 3;
+        const uint32_t i0 = corner_vertex(indices, 3 * f), i1 = corner_vertex(indices, 3 * f + 1), i2 = corner_vertex(indices, 3 * f + 2);
+#pragma unroll
+        for (uint32_t k = 0; k < NI; ++k) {
+            if (k >= ni) break;  // the crowd's last group may be short
+            const float* pos = pos0 + k * stride;
+            const float* p0 = pos + (size_t)i0 * 3; const float* p1 = pos + (size_t)i1 * 3; const float* p2 = pos + (size_t)i2 * 3;
+            // normalize((p2 - p1) x (p0 - p1)): face_unit_normal's operations, on indices already fetched
+            const float a[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+            const float d[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
+            const float c[3] = {a[1] * d[2] - d[1] * a[2], a[2] * d[0] - d[2] * a[0], a[0] * d[1] - d[0] * a[1]};
+            const float r = 1.0f / sqrtf((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
+            s[k][0] += c[0] * r; s[k][1] += c[1] * r; s[k][2] += c[2] * r;
+        }
     }
-    const float r = 1.0f / sqrtf((s0 * s0 + s1 * s1) + s2 * s2);
-    out[0] = s0 * r; out[1] = s1 * r; out[2] = s2 * r;
+#pragma unroll
+    for (uint32_t k = 0; k < NI; ++k) {
+        if (k >= ni) break;
+        const float r = 1.0f / sqrtf((s[k][0] * s[k][0] + s[k][1] * s[k][1]) + s[k][2] * s[k][2]);
+        float* o = out0 + k * stride;
+        o[0] = s[k][0] * r; o[1] = s[k][1] * r; o[2] = s[k][2] * r;
+    }
 }
 
 // Exclusive prefix sum of n counters (integers: exact in any order).  Three small kernels instead of a
@@ -338,9 +362,11 @@ hipError_t launch_topology(const uint32_t* indices, uint32_t vertices, uint32_t 
 hipError_t launch_crowd_normals(const float* pos_all, const uint32_t* indices, const uint32_t* start, const uint32_t* adj,
                                 uint32_t vertices, uint32_t first, uint32_t count, float* out_all, hipStream_t s) {
     if (vertices == 0) return hipSuccess;
-    for (uint32_t done = 0; done < count;) {  // gridDim.y holds at most 65,535 instances
-        const uint32_t n = count - done < 65535u ? count - done : 65535u;
-        hipLaunchKernelGGL(k_crowd_normals, dim3((vertices + 255) / 256, n), dim3(256), 0, s, pos_all, indices, start, adj, vertices, first + done, out_all);
+    for (uint32_t done = 0; done < count;) {  // gridDim.y holds at most 65,535 groups of kNormalsInstances instances
+        const uint32_t cap = 65535u * kNormalsInstances;
+        const uint32_t n = count - done < cap ? count - done : cap;
+        hipLaunchKernelGGL(k_crowd_normals, dim3((vertices + 255) / 256, (n + kNormalsInstances - 1) / kNormalsInstances), dim3(256), 0, s, pos_all,
+                           indices, start, adj, vertices, first + done, n, out_all);
         done += n;
     }
     return hipGetLastError();
