@@ -9,7 +9,8 @@
 // positions); morph deltas of the (tile, target) pairs with a non-zero weight reach the waves
 // through LDS slots.  Three kernels share the arithmetic below:
 //   k_skin2     tiles with <= 21 joints, <= 2 weight sets: four self-staging waves per block
-//   k_skin_fix  the (tile, instance) pairs k_skin2 hands over (3+ active pairs, compacted pairs)
+//   k_skin_fix  the (tile, instance) pairs k_skin2 hands over (3+ active pairs; every instance of the few tiles whose long
+//               joint lists would size k_skin2's palette ring)
 //   k_skin      everything else: four compute waves + one loader wave
 //
 // Arithmetic order is the WGSL's (renderer/src/shader/shader.wgsl:127-141, :159-163):
