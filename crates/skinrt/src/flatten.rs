@@ -15,6 +15,7 @@ use std::sync::Arc;
 use renderer_asset::animation::{AnimationAsset, AnimationKeyFrames, AnimationSampler};
 use renderer_asset::index::AssetIndex;
 use renderer_asset::node::{NodeAsset, NodeTransform};
+use renderer_asset::primitive::PrimitiveAssetMode;
 use renderer_asset::scene::SceneAsset;
 use renderer_asset::skin::SkinAsset;
 use skinrt_sys as sys;
@@ -76,6 +77,10 @@ pub struct FlatRig {
     pub default_weights: Vec<f32>,
     /// non-finite generated morph tangent deltas replaced by zero (see flatten.cpp)
     pub sanitized_tangent_deltas: u64,
+    /// triangle corners of every `TriangleList` primitive as indices into the RIG's vertex array (`PrimitiveAsset.indices`,
+    /// primitive.rs:43, offset by the primitive's first vertex; without indices: 3f, 3f+1, 3f+2 as tangent.rs:42-51 reads
+    /// it): what `Topology::new` takes for per-frame normals.  Whole triangles only (`len() / 3`, tangent.rs:29).
+    pub triangles: Vec<u32>,
 }
 
 /// What to take from the scenes (the defaults: everything).
@@ -311,6 +316,20 @@ pub fn flatten_with(scenes: &[SceneAsset], animations: &[AnimationAsset], opt: &
                 for v in 0..count {
                     rig.joints[k].extend_from_slice(&if have { at.joints[k][v] } else { [0u16; 4] });
                     rig.weights[k].extend_from_slice(&if have { at.weights[k][v] } else { [0.0f32; 4] });
+                }
+            }
+            if matches!(p.mode, PrimitiveAssetMode::TriangleList) {
+                let first = (rig.position.len() / 3 - count) as u32;
+                match &p.indices {
+                    Some(idx) => {
+                        for &i in &idx[..idx.len() / 3 * 3] {
+                            if i as usize >= count {
+                                return Err(Error::new(sys::SKINRT_E_RANGE, "primitive index beyond its positions (reference: index panic, tangent.rs:35)"));
+                            }
+                            rig.triangles.push(first + i);
+                        }
+                    }
+                    None => rig.triangles.extend((0..(count / 3 * 3) as u32).map(|c| first + c)),
                 }
             }
             for (m, src) in p.targets.iter().enumerate() {

@@ -220,6 +220,17 @@ int flatten(const std::vector<SceneAsset>& scenes, const std::vector<AnimationAs
                     }
                 }
             }
+            if (p.mode == PrimitiveAssetMode::TriangleList) {
+                if (p.indices) {
+                    const size_t whole = p.indices->size() / 3 * 3;
+                    for (size_t c = 0; c < whole; ++c) {
+                        if ((*p.indices)[c] >= n) return fail(err, SKINRT_E_RANGE, "primitive index beyond its positions (reference: index panic, tangent.rs:35)");
+                        rig.triangles.push_back(first + (*p.indices)[c]);
+                    }
+                } else {
+                    for (size_t c = 0; c < n / 3 * 3; ++c) rig.triangles.push_back(first + (uint32_t)c);
+                }
+            }
             rig.ranges.push_back({mr.node, (uint32_t)pi, first, (uint32_t)n, section_index});
         }
         sec.vertex_count = rig.vertex_count() - sec.first_vertex;

@@ -74,6 +74,11 @@ struct FlatRig {
     std::vector<float> default_weights;
     uint64_t sanitized_tangent_deltas = 0;         // non-finite morph tangent deltas replaced by zero (flatten.cpp)
     std::vector<PrimitiveRange> ranges;
+    // triangle corners of every TriangleList primitive as indices into the RIG's vertex array (PrimitiveAsset.indices,
+    // primitive.rs:47, offset by the primitive's first vertex; a primitive without indices contributes 3f, 3f+1, 3f+2 as
+    // calculate_tangent reads it, tangent.rs:42-51): what skinrt_create_topology takes for per-frame normals.  Whole
+    // triangles only (len() / 3 per primitive, tangent.rs:29); other modes have no faces.
+    std::vector<uint32_t> triangles;
 
     uint32_t node_count() const { return (uint32_t)parent.size(); }
     uint32_t vertex_count() const { return (uint32_t)(position.size() / 3); }

@@ -7,6 +7,9 @@
 #include <cstdlib>
 #include <functional>
 
+#include <cstring>
+
+#include "gltf_loader.hpp"
 #include "skinned_scene.hpp"
 
 using namespace skinrt_host;
@@ -332,6 +335,21 @@ static void gpu_checks() {
     const auto verts = scene.texture_skin_vertices(1);
     EXPECT(verts.size() == 5 && verts[3].joint_index[0] == 2 && verts[3].joint_weight[0] == 1.0f);
     EXPECT(std::fabs(verts[3].position[0] - 6.0f) < 1e-6);
+    // per-frame normals from the deformed positions: the flattener kept the scene's triangle list (primitive 0: three
+    // vertices without indices = one triangle; primitive 1 has two vertices: none), the device runs calculate_tangent per
+    // instance on the skinned positions — bit for bit the host restatement on the same positions
+    EXPECT(scene.rig().triangles.size() == 3 && scene.rig().triangles[2] == 2);
+    scene.recompute_normals(0, 2);
+    scene.synchronize();
+    const auto nrm = scene.download<float>(skinrt_get_normals);
+    for (int i = 0; i < 2; ++i) {
+        std::vector<std::array<float, 3>> p(5), want;
+        for (int v = 0; v < 5; ++v) p[v] = {pos[(i * 5 + v) * 3], pos[(i * 5 + v) * 3 + 1], pos[(i * 5 + v) * 3 + 2]};
+        const std::vector<uint32_t> tri = scene.rig().triangles;
+        EXPECT(calculate_tangent(PrimitiveAssetMode::TriangleList, p, &tri, want));
+        for (int v = 0; v < 3; ++v) EXPECT(std::memcmp(&nrm[(i * 5 + v) * 3], want[v].data(), 12) == 0 && std::isfinite(want[v][0]));
+        for (int v = 3; v < 5; ++v) EXPECT(std::isnan(nrm[(i * 5 + v) * 3]) && std::isnan(want[v][0]));
+    }
 }
 
 static void gpu_checks_multi() {

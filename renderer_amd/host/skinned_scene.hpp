@@ -90,6 +90,17 @@ public:
 
     void render(uint32_t stages = SKINRT_STAGE_ALL) { check(skinrt_evaluate(crowd_, stages)); }
     void synchronize() { check(skinrt_synchronize(ctx_)); }
+    // Normals (or tangents) of what the frame produced: calculate_tangent (tangent.rs:15-58) per instance on the skinned
+    // positions, over the scene's triangle lists (FlatRig::triangles); enqueued behind render().  The topology is built on
+    // first use.  The reference runs the generator once, at load, on the bind pose (loader/gltf/mod.rs:1086-1089).
+    void recompute_normals(uint32_t first, uint32_t count, uint32_t output = SKINRT_OUTPUT_NORMALS) {
+        if (!topology_) {
+            static const uint32_t none = 0;  // a scene without triangle lists has NO faces (a NULL list would mean "every three vertices")
+            check(skinrt_create_topology(ctx_, flat_.vertex_count(), flat_.triangles.empty() ? &none : flat_.triangles.data(),
+                                         (uint32_t)flat_.triangles.size(), &topology_));
+        }
+        check(skinrt_recompute_normals(crowd_, topology_, first, count, output));
+    }
 
     // SkinUniformBuffer::update for one instance and one of the scene's skins: 128 SkinMatrix entries, unused ones zero
     std::vector<SkinMatrix> skin_uniform(uint32_t instance, uint32_t skin = 0) {
@@ -134,15 +145,17 @@ public:
 
 private:
     void release() {
+        if (topology_) skinrt_destroy_topology(topology_);
         if (crowd_) skinrt_destroy_crowd(crowd_);
         if (rig_) skinrt_destroy_rig(rig_);
         if (ctx_) skinrt_destroy_ctx(ctx_);
-        crowd_ = nullptr; rig_ = nullptr; ctx_ = nullptr;
+        topology_ = nullptr; crowd_ = nullptr; rig_ = nullptr; ctx_ = nullptr;
     }
     FlatRig flat_;
     skinrt_ctx* ctx_ = nullptr;
     skinrt_rig* rig_ = nullptr;
     skinrt_crowd* crowd_ = nullptr;
+    skinrt_topology* topology_ = nullptr;
     uint32_t instances_ = 0;
 };
 
