@@ -71,6 +71,12 @@ __device__ unsigned long long g_stamps[16];
 #ifndef SKINRT_SPARSE_SLOTS
 #define SKINRT_SPARSE_SLOTS 1
 #endif
+// 0 (the product): the skin kernels walk a crowd's instances from the last range to the first, so that the palettes the
+// pose stage wrote most recently (still in the memory-side cache) are the first ones read; bit 0: k_skin2 / k_skin
+// ascending, bit 1: k_skin_fix walks its lists upwards (A/B builds; same results).  See k_skin2's block mapping.
+#ifndef SKINRT_RANGE_ORDER
+#define SKINRT_RANGE_ORDER 0
+#endif
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -409,8 +415,9 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
     const uint32_t xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
     const uint32_t tc = xcd % plan.tile_chunks, rc = xcd / plan.tile_chunks;
     const uint32_t tile = tc * plan.tiles_per_chunk + k % plan.tiles_per_chunk;
-    const uint32_t rng = rc * plan.ranges_per_chunk + k / plan.tiles_per_chunk;
+    uint32_t rng = rc * plan.ranges_per_chunk + k / plan.tiles_per_chunk;
     if (tile >= rig.T || rng >= plan.ranges) return;
+    if (!(SKINRT_RANGE_ORDER & 1)) rng = plan.ranges - 1 - rng;  // last range first: see k_skin2
     // tiles whose joint list fits LDS are skinned by the LDSPAL=true launch, the rest (rare: no
     // joint locality) by the LDSPAL=false launch that gathers the palette from L2
     {
@@ -1000,7 +1007,11 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
     const uint32_t stride = chunk_lanes * kFixChunk;
     uint32_t e0 = chunk_lane * kFixChunk;
     uint32_t ents = 0;  // the chunk's instances in one load (lane k = entry e0 + k)
-    if (e0 + lane < count && lane < kFixChunk) ents = list[e0 + lane];
+    // (the list is walked from its END, k_classify having filled it roughly in ascending instance order: like k_skin2's
+    // ranges, so that the two kernels ask for the same instances' palettes at about the same time)
+    if (!(SKINRT_RANGE_ORDER & 2)) list += count - 1;
+    constexpr int kListStep = (SKINRT_RANGE_ORDER & 2) ? 1 : -1;
+    if (e0 + lane < count && lane < kFixChunk) ents = list[kListStep * (int)(e0 + lane)];
     uint32_t inst[kFixBatch];
     f4 piece[kFixBatch];
     float mwq[kFixBatch];  // lane q: weight of pair q (first 64 pairs) for instance b; 0 for b past the batch's end
@@ -1018,7 +1029,7 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
         const uint32_t e1 = min(count, e0 + kFixChunk);
         const uint32_t e0n = e0 + stride;  // this block's next chunk
         uint32_t ents_next = 0;
-        if (e0n + lane < count && lane < kFixChunk) ents_next = list[e0n + lane];
+        if (e0n + lane < count && lane < kFixChunk) ents_next = list[kListStep * (int)(e0n + lane)];
         for (uint32_t b0 = e0; b0 < e1; b0 += kFixBatch) {
             const uint32_t nb = min(kFixBatch, e1 - b0);
             // the batch after this one: the rest of the chunk, else the head of the next chunk
@@ -1165,9 +1176,15 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     // (plan.run2 = tiles per run: 1 = fully interleaved, tiles_per_chunk2 = one contiguous chunk per XCD)
     const uint32_t jt = kblk % plan.tiles_per_chunk2;
     const uint32_t tile = ((jt / plan.run2) * plan.tile_chunks + tc) * plan.run2 + jt % plan.run2;
-    const uint32_t rng = rc * plan.ranges_per_chunk2 + kblk / plan.tiles_per_chunk2;
+    uint32_t rng = rc * plan.ranges_per_chunk2 + kblk / plan.tiles_per_chunk2;
     if (tile >= rig.T || rng >= plan.ranges2) return;
     if (rig.tile_lds[tile] != 2) return;  // other tiles: k_skin
+    // The grid walks the instance ranges from the LAST to the first.  The pose stage has just written the palettes in
+    // ascending instance order, and what of them is still in the memory-side cache (256 MB, written lines allocate,
+    // least recently written go first) is the END of the crowd: C3's pose stage writes 0.4 GB, so walking upwards
+    // every first touch of a palette row went to HBM, against the store stream (round 3: 4.19-4.22 -> 4.06 ms;
+    // tools/exp_split.py).  SKINRT_RANGE_ORDER=3 (measurement builds): ascending, as until then.
+    if (!(SKINRT_RANGE_ORDER & 1)) rng = plan.ranges2 - 1 - rng;
     const uint32_t i0 = rng * plan.range2;
     const uint32_t i1 = min(cr.I, i0 + plan.range2);
     const uint32_t nin = i1 - i0;  // <= kSkin2Range
@@ -1675,7 +1692,7 @@ uint32_t skin_build_flags() {
     f |= SKINRT_BUILD_STAMPS;
 #endif
     if (SKINRT_RANGE2 != 80 || SKINRT_MORPH_SLOTS != 2 || SKINRT_INFLIGHT != 2 || SKINRT_BLOCKS_K1 != 5 || SKINRT_ORDER_ROT != 23u ||
-        SKINRT_STORE_POLICY != 1 || sizeof(SKINRT_PAL_MOD) != 1 || SKINRT_SPARSE_SLOTS != 1 || SKINRT_FIX_BATCH != 0)
+        SKINRT_STORE_POLICY != 1 || sizeof(SKINRT_PAL_MOD) != 1 || SKINRT_SPARSE_SLOTS != 1 || SKINRT_FIX_BATCH != 0 || SKINRT_RANGE_ORDER != 0)
         f |= SKINRT_BUILD_TUNING;
     return f;
 }
