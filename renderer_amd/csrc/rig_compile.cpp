@@ -463,6 +463,19 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
             r.morph_entries++;
         }
     }
+    // A rig with ANY compacted pair runs k_skin2's SPARSE instantiations, which carry a layout bit per pair through the
+    // instance loop of every tile (C3 +2.5 %, C5 +6.6 %: profiles/r03_ubench.txt).  Where compacted pairs are a small
+    // minority — a target cut in two by a mesh-section boundary inside a tile, the rim of a morphed region — storing
+    // them dense as well (zeros elsewhere: w * 0 adds exactly 0, same sums) costs 9 KB each and keeps the whole crowd
+    // on the dense-only kernels.  Rigs made of small targets keep the compact layout.
+    bool promote = false;
+    {
+        uint64_t n_pairs = 0, n_compact = 0;
+        for (uint32_t t = 0; t < T; ++t)
+            for (const PairTmp& pt : per_tile[t]) { ++n_pairs; n_compact += pt.lv.size() < kMorphDenseMin ? 1 : 0; }
+        promote = n_compact > 0 && n_compact * 8 <= n_pairs && n_compact * 9 * TV * sizeof(float) <= (64ull << 20);
+        r.promoted_pairs = promote ? (uint32_t)n_compact : 0;
+    }
     r.tile_pair_start.assign(T + 1, 0);
     r.max_tile_pairs = 0;
     for (uint32_t t = 0; t < T; ++t) {
@@ -472,7 +485,7 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
         for (const PairTmp& pt : per_tile[t]) {
             MorphPair mp{};
             mp.target = (uint16_t)pt.target;
-            mp.dense = pt.lv.size() >= kMorphDenseMin ? 1 : 0;
+            mp.dense = (promote || pt.lv.size() >= kMorphDenseMin) ? 1 : 0;
             mp.data_off = (uint32_t)r.mblock.size();
             if (mp.dense) {
                 mp.floats = 9 * TV;

@@ -133,6 +133,7 @@ struct CompiledRig {
     std::vector<float> default_weights; // [M]
     uint32_t max_tile_pairs = 0;
     uint64_t morph_entries = 0;         // nonzero (vertex, target) deltas kept
+    uint32_t promoted_pairs = 0;        // (tile, target) pairs small enough to compact but stored dense (see compile_impl)
     // kept for skinrt_export_interleaved
     std::vector<uint16_t> joints0;      // [V][4] (indices into the vertex's own skin, as given; zeros for un-skinned sections)
     std::vector<float> weights0;        // [V][4]
