@@ -1,0 +1,142 @@
+// rig_compile_selftest.cpp — host-only checks of rig-compiler POLICIES that the C ABI does not report (test
+// infrastructure: built by `make selftest`, run by tests/test_rig_compiler.py; links rig_compile.o directly).
+//
+//  * morph pairs: a (tile, target) pair touching fewer than kMorphDenseMin vertices is stored compacted, and ANY
+//    compacted pair puts the whole rig on k_skin2's SPARSE instantiations — unless such pairs are a small minority
+//    (at most an eighth of the pairs, at most 64 MB as dense blocks), in which case they are stored dense too
+//    (CompiledRig::promoted_pairs).  The stored deltas must be the same either way.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rig_compile.hpp"
+
+using namespace skinrt;
+
+namespace {
+
+int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+// One joint, `vertices` vertices bound to it, and compacted-form targets given as lists of touched vertices.
+struct TinyRig {
+    std::vector<int32_t> parent{-1};
+    std::vector<float> t{0, 0, 0}, r{0, 0, 0, 1}, s{1, 1, 1};
+    std::vector<uint32_t> joint_node{0};
+    std::vector<float> pos, nrm, tan, w;
+    std::vector<uint16_t> j;
+    std::vector<std::vector<uint32_t>> touched;
+    std::vector<std::vector<float>> delta;
+    std::vector<skinrt_morph_target_desc> targets;
+    const uint16_t* jp[1];
+    const float* wp[1];
+    skinrt_rig_desc desc{};
+
+    TinyRig(uint32_t vertices, const std::vector<std::vector<uint32_t>>& lists) : touched(lists) {
+        pos.assign((size_t)vertices * 3, 0.25f); nrm.assign((size_t)vertices * 3, 0.0f); tan.assign((size_t)vertices * 3, 0.0f);
+        for (uint32_t v = 0; v < vertices; ++v) { nrm[v * 3 + 2] = 1.0f; tan[v * 3] = 1.0f; }
+        j.assign((size_t)vertices * 4, 0); w.assign((size_t)vertices * 4, 0.0f);
+        for (uint32_t v = 0; v < vertices; ++v) w[v * 4] = 1.0f;
+        for (size_t m = 0; m < touched.size(); ++m) {
+            delta.emplace_back(touched[m].size() * 3);
+            for (size_t k = 0; k < touched[m].size(); ++k)
+                for (int e = 0; e < 3; ++e) delta[m][k * 3 + e] = 0.5f + (float)m + 0.001f * (float)touched[m][k] + (float)e;
+        }
+        for (size_t m = 0; m < touched.size(); ++m)
+            targets.push_back(skinrt_morph_target_desc{(uint32_t)touched[m].size(), touched[m].data(), delta[m].data(), nullptr, nullptr});
+        jp[0] = j.data(); wp[0] = w.data();
+        desc.struct_size = sizeof(desc);
+        desc.node_count = 1; desc.parent = parent.data(); desc.translation = t.data(); desc.rotation = r.data(); desc.scale = s.data();
+        desc.joint_count = 1; desc.joint_node = joint_node.data();
+        desc.vertex_count = vertices; desc.position = pos.data(); desc.normal = nrm.data(); desc.tangent = tan.data(); desc.tangent_stride = 3;
+        desc.set_count = 1; desc.joints = jp; desc.weights = wp;
+        desc.target_count = (uint32_t)targets.size(); desc.targets = targets.data();
+    }
+};
+
+std::vector<uint32_t> run(uint32_t first, uint32_t count) {
+    std::vector<uint32_t> v(count);
+    for (uint32_t k = 0; k < count; ++k) v[k] = first + k;
+    return v;
+}
+
+// the x delta the compiled rig holds for (pair, tile lane), whatever the pair's layout
+float stored_dx(const CompiledRig& r, const MorphPair& mp, uint32_t lane) {
+    const float* blk = &r.mblock[mp.data_off];
+    if (mp.dense) return blk[(lane / 64) * kMorphWaveFloats + 0 * 64 + (lane % 64)];
+    const uint8_t slot = reinterpret_cast<const uint8_t*>(blk)[lane];
+    return slot ? blk[kTileVerts / 4 + (size_t)(slot - 1) * 9] : 0.0f;
+}
+
+}  // namespace
+
+int main() {
+    std::string why;
+    // 16 targets over whole tiles (dense pairs) + 1 target of 10 vertices: 1 of 17 pairs is small -> stored dense
+    {
+        std::vector<std::vector<uint32_t>> lists;
+        for (uint32_t m = 0; m < 16; ++m) lists.push_back(run((m % 4) * kTileVerts, kTileVerts));
+        lists.push_back(run(300, 10));
+        TinyRig rig(4 * kTileVerts, lists);
+        CompiledRig c;
+        CHECK(compile_rig(&rig.desc, nullptr, c, why) == SKINRT_OK);
+        CHECK(c.pairs.size() == 17);
+        CHECK(c.promoted_pairs == 1);
+        for (const MorphPair& mp : c.pairs) CHECK(mp.dense == 1);
+        // the promoted pair's deltas: the 10 touched lanes of tile 1 carry their values, every other lane an exact zero
+        const MorphPair* small = nullptr;
+        for (const MorphPair& mp : c.pairs) if (mp.target == 16) small = &mp;
+        CHECK(small != nullptr);
+        if (small)
+            for (uint32_t lane = 0; lane < kTileVerts; ++lane) {
+                const uint32_t v = kTileVerts + lane;
+                const float want = (v >= 300 && v < 310) ? rig.delta[16][(v - 300) * 3] : 0.0f;
+                CHECK(stored_dx(c, *small, lane) == want);
+            }
+    }
+    // 4 dense pairs + 4 small ones: half the pairs are small -> the compact layout stays
+    {
+        std::vector<std::vector<uint32_t>> lists;
+        for (uint32_t m = 0; m < 4; ++m) lists.push_back(run(m * kTileVerts, kTileVerts));
+        for (uint32_t m = 0; m < 4; ++m) lists.push_back(run(m * kTileVerts + 7, 12));
+        TinyRig rig(4 * kTileVerts, lists);
+        CompiledRig c;
+        CHECK(compile_rig(&rig.desc, nullptr, c, why) == SKINRT_OK);
+        CHECK(c.pairs.size() == 8);
+        CHECK(c.promoted_pairs == 0);
+        uint32_t compact = 0;
+        for (const MorphPair& mp : c.pairs) {
+            compact += mp.dense ? 0 : 1;
+            if (!mp.dense) {
+                const uint32_t tile = (uint32_t)(mp.target - 4);
+                for (uint32_t lane = 0; lane < kTileVerts; ++lane) {
+                    const float want = (lane >= 7 && lane < 19) ? rig.delta[mp.target][(lane - 7) * 3] : 0.0f;
+                    CHECK(stored_dx(c, mp, lane) == want);
+                }
+                (void)tile;
+            }
+        }
+        CHECK(compact == 4);
+    }
+    // a rig of small targets only: nothing to promote
+    {
+        std::vector<std::vector<uint32_t>> lists;
+        for (uint32_t m = 0; m < 5; ++m) lists.push_back(run(40 * m, 8));
+        TinyRig rig(kTileVerts, lists);
+        CompiledRig c;
+        CHECK(compile_rig(&rig.desc, nullptr, c, why) == SKINRT_OK);
+        CHECK(c.promoted_pairs == 0);
+        for (const MorphPair& mp : c.pairs) CHECK(mp.dense == 0);
+    }
+    // no targets at all
+    {
+        TinyRig rig(kTileVerts, {});
+        CompiledRig c;
+        CHECK(compile_rig(&rig.desc, nullptr, c, why) == SKINRT_OK);
+        CHECK(c.promoted_pairs == 0 && c.pairs.empty());
+    }
+    if (failures) { std::printf("rig compiler selftest: %d check(s) failed (%s)\n", failures, why.c_str()); return 1; }
+    std::printf("rig compiler selftest ok\n");
+    return 0;
+}
