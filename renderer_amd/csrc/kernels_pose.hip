@@ -207,13 +207,15 @@ __device__ __forceinline__ void clear_unused_keys(const RigDev& rig, uint32_t cl
 
 // ---- wavefront-per-instance ------------------------------------------------------------
 // local_t != nullptr: the local matrices were sampled by k_sample_nodes (lane = instance; see there) and are
-// read from local_t[node][instance][12]; else they are sampled here, lane = node.
+// read from local_t[instance][node][12] — one contiguous run per wave; with [node][instance] a wave's 64 lanes touched
+// 64 rows 480 KB apart per load (round 3: this kernel 0.145 -> 0.114 ms on C3, the writer 0.114 -> 0.124); else they
+// are sampled here, lane = node.
 __global__ __launch_bounds__(64) void k_pose_wave(const RigDev rig, const CrowdDev cr, const uint32_t quirk, const float* __restrict__ local_t) {
     extern __shared__ float4 node_s[];  // [N][3] rows
     const uint32_t i = blockIdx.x, lane = threadIdx.x;
     if (local_t) {
         for (uint32_t n = lane; n < rig.N; n += 64) {
-            const Rows l = load_rows(local_t + ((size_t)n * cr.I + i) * 12);
+            const Rows l = load_rows(local_t + ((size_t)i * rig.N + n) * 12);  // [instance][node]: this kernel's layout (launch_pose)
             node_s[n * 3 + 0] = l.r0; node_s[n * 3 + 1] = l.r1; node_s[n * 3 + 2] = l.r2;
         }
     } else {
@@ -259,11 +261,12 @@ __global__ __launch_bounds__(64) void k_pose_wave(const RigDev rig, const CrowdD
 // instances.  When they play the same clip (the common case) every table load of the wave — channel record, key
 // times of the binary search, key values — falls into the same one or two cache lines, where the lane = node
 // mapping touched 64 different lines per load (C3: 619 such loads per wave, the pose stage's largest cost).  The
-// arithmetic is node_local()'s, so key indices and matrices are bit-identical.  Output: local_t[n][i][12], 48
-// contiguous bytes per lane = fully coalesced; the consumers read it back with a stride (k_pose_wave,
-// k_propagate_quad), which costs less than scattered partial-line writes would.
+// arithmetic is node_local()'s, so key indices and matrices are bit-identical.  Output, in the layout its consumer
+// wants: local_t[n][i][12] for the chain kernels (k_propagate_ring / _quad: lane = instance there too; 48 contiguous
+// bytes per lane = fully coalesced), local_t[i][n][12] for k_pose_wave (inst_major: 48-byte pieces 12.5 KB apart —
+// the writer pays 10 us for what saves the reader 30).
 __global__ __launch_bounds__(256) void k_sample_nodes(const RigDev rig, const CrowdDev cr, const uint32_t quirk, float* __restrict__ local_t,
-                                                      const uint32_t iblocks) {
+                                                      const uint32_t iblocks, const uint32_t inst_major) {
     const uint32_t n = blockIdx.x / iblocks, i = (blockIdx.x - n * iblocks) * 256 + threadIdx.x;
     if (n >= rig.N || i >= cr.I) return;
     const uint32_t clip = cr.clip[i];
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256) void k_sample_nodes(const RigDev rig, const Cr
     uint32_t* keyrow = cr.keyidx + (size_t)i * rig.Cmax;
     if (n == 0) clear_unused_keys(rig, clip, has_clip, keyrow, 0, 1);
     const Rows l = node_local(rig, clip, has_clip, n, cr.tau[i], quirk, keyrow);
-    store_rows(local_t + ((size_t)n * cr.I + i) * 12, l);
+    store_rows(local_t + (inst_major ? (size_t)i * rig.N + n : (size_t)n * cr.I + i) * 12, l);
 }
 
 // ---- split path -----------------------------------------------------------------------------
@@ -633,7 +636,7 @@ hipError_t launch_pose(const RigDev& rig, const CrowdDev& cr, uint32_t quirk, Po
     if (local_t) {
         const uint32_t iblocks = (cr.I + 255) / 256;
         if ((uint64_t)iblocks * rig.N > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_sample_nodes, dim3(iblocks * rig.N), dim3(256), 0, s, rig, cr, quirk, local_t, iblocks);
+        hipLaunchKernelGGL(k_sample_nodes, dim3(iblocks * rig.N), dim3(256), 0, s, rig, cr, quirk, local_t, iblocks, path == kPoseWave ? 1u : 0u);
     }
     if (path == kPoseWave) {
         const size_t lds = (size_t)rig.N * 48;
