@@ -596,7 +596,9 @@ int skinrt_evaluate(skinrt_crowd* c, uint32_t mask) {
     HIP_TRY(hipEventRecord(c->ev[1], s));
     if (mask & SKINRT_STAGE_SKIN) {
         SkinPlan p = c->plan;
-        p.aabb = (mask & SKINRT_STAGE_AABB) ? 1 : 0;
+        // 2: k_skin2 writes its bounds records non-temporally — where the crowd's palettes compete for the memory-side cache
+        // (see k_skin2's epilogue); small crowds keep them cached for k_aabb_reduce
+        p.aabb = (mask & SKINRT_STAGE_AABB) ? ((uint64_t)cr.I * rig.J * 96 >= (64ull << 20) ? 2 : 1) : 0;
         SkinConcurrency conc{c->ctx->side, c->ev[4], c->ev[5]};
         conc.skin2_first = c->ctx->env.fix_order;
         conc.fix_blocks = c->ctx->env.fix_blocks;

@@ -1493,10 +1493,18 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
         if (tid < nproc) {
             const float* cell = bb_s + tid * 6;
             float* dst = cr.aabb_part + ((size_t)hdr_s[tid].y * rig.T + tile) * 6;
+            // non-temporal on large crowds (plan.aabb == 2, skinrt_evaluate): 56 MB of records per C3 frame would otherwise sit
+            // in the memory-side cache in place of palettes this stage has yet to read (stage -0.02 ms, k_aabb_reduce +0.009
+            // reading them from HBM).  Small crowds, whose palettes fit that cache with room to spare, keep plain stores
+            // (C2 +5 % with nt).
+            if (plan.aabb == 2) {
 #pragma unroll
-            // non-temporal: 56 MB of records per C3 frame would otherwise sit in the memory-side cache in place of palettes
-            // this stage has yet to read (stage -0.02 ms, k_aabb_reduce +0.009 reading them from HBM)
-            for (int c = 0; c < 6; ++c) __builtin_nontemporal_store(c < 3 ? -cell[c] : cell[c], dst + c);
+                for (int c = 0; c < 6; ++c)  // asm: as two branches of builtin stores the compiler merges them and drops the hint
+                    asm volatile("global_store_dword %0, %1, off nt" : : "v"(dst + c), "v"(c < 3 ? -cell[c] : cell[c]) : "memory");
+            } else {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) dst[c] = c < 3 ? -cell[c] : cell[c];
+            }
         }
     }
 }
