@@ -235,6 +235,40 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg, c
 
 bool affine_last_row(const float* m) { return m[3] == 0.0f && m[7] == 0.0f && m[11] == 0.0f && m[15] == 1.0f; }
 
+// ---- do the context's two streams really run side by side? ------------------------------------------------------------
+// HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and two streams on one queue run their
+// kernels one after the other.  In a process that already holds streams of its own — a host running torch + RCCL beside
+// the library: bench.py under torchrun — the side stream came to share the main stream's queue: k_skin_fix then ran
+// BEHIND k_skin2 instead of beside it and the skin stage took 4.29 ms instead of 4.04 on C3 (round 3; identical to
+// SKINRT_FIX_STREAM=0).  So skinrt_init measures it: a kernel that holds the main stream for 0.2 ms, an empty one on the
+// side stream, and the side stream's event tells whether it had to wait.  A side stream that waits is replaced (the
+// runtime hands the next stream another queue); the streams tried are kept alive until the choice is made.
+__global__ void k_hold(uint64_t ticks) {  // leaves after `ticks` of the constant-rate clock: an exit every wave reaches
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void k_nothing() {}
+
+hipError_t side_by_side(int device, hipStream_t main, hipStream_t side, hipEvent_t e0, hipEvent_t e1, bool* concurrent) {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+    const uint64_t hold = (uint64_t)khz / 5;  // 0.2 ms
+    float ms = 0.0f;
+    for (int pass = 0; pass < 2; ++pass) {  // the first pass creates queues and loads code; the second is the measurement
+        hipError_t e = hipEventRecord(e0, main);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_hold, dim3(1), dim3(64), 0, main, pass ? hold : (uint64_t)1);
+        hipLaunchKernelGGL(k_nothing, dim3(1), dim3(64), 0, side);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipEventRecord(e1, side)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(main)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(side)) != hipSuccess) return e;
+        if ((e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) { (void)hipGetLastError(); ms = 0.0f; }  // (the side event before e0: it did not wait)
+    }
+    *concurrent = ms < 0.1f;
+    return hipSuccess;
+}
+
 int check_crowd(skinrt_crowd* c) {
     if (!c || !c->ctx || !c->rig) return fail(SKINRT_E_INVALID, "crowd handle is NULL");
     return SKINRT_OK;
@@ -296,12 +330,31 @@ int skinrt_init(const skinrt_config* config, skinrt_ctx** out_ctx) {
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // lo = least urgent (largest number)
             const int want = ctx->env.fix_prio;  // -1 urgent, 0 default (the product), 1 least urgent — see profiles/r03_ubench.txt: k_skin_fix ends 0.18 ms after
                                                  // k_skin2 on C3 at the least urgent priority; at the default one the two end closer together
-            e = hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, want < 0 ? hi : (want > 0 ? lo : (lo + hi) / 2));
+            const int prio = want < 0 ? hi : (want > 0 ? lo : (lo + hi) / 2);
+            e = hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, prio);
             if (e != hipSuccess) {
                 (void)hipStreamDestroy(ctx->stream);
                 delete ctx;
                 return fail(SKINRT_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
             }
+            // a side stream that shares the main stream's hardware queue is no side stream: look for one that does not
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+                std::vector<hipStream_t> tried;
+                for (int attempt = 0; attempt < 8; ++attempt) {
+                    bool concurrent = true;
+                    if (side_by_side(config->device, ctx->stream, ctx->side, e0, e1, &concurrent) != hipSuccess) { (void)hipGetLastError(); break; }
+                    if (concurrent) break;
+                    hipStream_t next = nullptr;
+                    if (hipStreamCreateWithPriority(&next, hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); break; }
+                    tried.push_back(ctx->side);
+                    ctx->side = next;
+                }
+                for (hipStream_t t : tried) (void)hipStreamDestroy(t);
+            }
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            (void)hipGetLastError();
         }
     }
     *out_ctx = ctx;
