@@ -111,7 +111,7 @@ typedef struct skinrt_config {
      *    (sample / lane-per-instance propagate / palette) used for very deep or large rigs. */
     uint32_t pose_path;
     /* 0: choose per tile; 1: only the loader-wave skinning kernel (the self-staging kernel, used
-     *    for tiles with at most 21 joints and rigs with at most 2 weight sets, is switched off). */
+     *    for tiles with at most 42 joints and rigs with at most 2 weight sets, is switched off). */
     uint32_t skin_path;
     /* Where skinrt_create_crowd puts the position / normal / tangent arrays of a large crowd
      * (3 arrays >= 1 GiB together).  0: one array per third of the device's physical HBM address

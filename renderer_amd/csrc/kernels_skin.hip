@@ -8,7 +8,7 @@
 // in LDS (rig_compile builds per-tile joint lists and rewrites the vertex indices to list
 // positions); morph deltas of the (tile, target) pairs with a non-zero weight reach the waves
 // through LDS slots.  Three kernels share the arithmetic below:
-//   k_skin2     tiles with <= 21 joints, <= 2 weight sets: four self-staging waves per block
+//   k_skin2     tiles with <= 42 joints, <= 2 weight sets: four self-staging waves per block
 //   k_skin_fix  the (tile, instance) pairs k_skin2 hands over (3+ active pairs; every instance of the few tiles whose long
 //               joint lists would size k_skin2's palette ring)
 //   k_skin      everything else: four compute waves + one loader wave
@@ -949,17 +949,20 @@ constexpr uint32_t kFixChunk = 8;
 #ifndef SKINRT_FIX_BATCH
 #define SKINRT_FIX_BATCH 0
 #endif
-constexpr uint32_t kFixLdsBytes = 2 * 128 * 16 + 4 * 6 * 4 + 32 + 64 * sizeof(MorphPair);  // of the block's dynamic LDS
+// dynamic LDS of a k_skin_fix block: two palette staging buffers of `pieces` 16-byte pieces (SkinPlan::fix_pieces: 128, or 256 where
+// tiles with more than 21 joints are served), bounds partials, the tile's first 64 pair records
+constexpr uint32_t fix_lds_bytes(uint32_t pieces) { return 2 * pieces * 16 + 4 * 6 * 4 + 32 + 64 * (uint32_t)sizeof(MorphPair); }
 // fb = this block's index among the kernel's `fix_blocks` blocks (a multiple of 8 * ceil(T / 8))
-template <int AR, int K, bool SKIP, int BATCH>
+template <int AR, int K, bool SKIP, int BATCH, uint32_t PIECES>
 __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, float4* smem, uint32_t fb, uint32_t fix_blocks) {
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
     constexpr bool EXACT = AR != 0, NEXACT = AR == 1;  // AR 2: positions contraction-free, normals / tangents fused
     constexpr uint32_t kFixBatch = SKINRT_FIX_BATCH ? SKINRT_FIX_BATCH : (uint32_t)BATCH;
     static_assert(kFixChunk % kFixBatch == 0, "a chunk is a whole number of batches");
-    f4 (*pal_s)[128] = reinterpret_cast<f4 (*)[128]>(smem);                            // [2][128]
-    float (*part)[6] = reinterpret_cast<float (*)[6]>(pal_s + 2);                        // [4][6] (+ 32 B pad)
+    constexpr uint32_t pcap = PIECES;                                                     // 128 or 256 (= plan.fix_pieces)
+    f4* pal_s = reinterpret_cast<f4*>(smem);                                             // [2][pcap]
+    float (*part)[6] = reinterpret_cast<float (*)[6]>(pal_s + 2 * pcap);                 // [4][6] (+ 32 B pad)
     MorphPair* pairs_l = reinterpret_cast<MorphPair*>(reinterpret_cast<char*>(part) + 4 * 6 * 4 + 32);  // the tile's first 64 pair records
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // block -> (tile, chunk lane): consecutive block ids go round-robin to the 8 XCDs; every block of
@@ -991,7 +994,7 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
     }
     const uint32_t ninf = SKIP ? wave_influences<K>(w) : 4u * K;
     const uint32_t jstart = rig.tile_joint_start[tile];
-    const uint32_t npieces = (rig.tile_joint_start[tile + 1] - jstart) * 6;  // <= 126 for k_skin2's tiles
+    const uint32_t npieces = (rig.tile_joint_start[tile + 1] - jstart) * 6;  // <= plan.fix_pieces (<= 256 = the block's threads) for k_skin2's tiles
     const uint32_t joff = tid < npieces ? rig.tile_joints[jstart + tid / 6] * 6 + tid % 6 : 0u;
     const uint32_t pbeg = rig.tile_pair_start[tile], pend = rig.tile_pair_start[tile + 1];
     if (tid < min(pend - pbeg, 64u)) pairs_l[tid] = rig.pairs[pbeg + tid];
@@ -1089,7 +1092,7 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
                 if (b >= nb) continue;  // block-uniform
                 // stage this instance's palette rows; the buffers alternate, so the one barrier below
                 // also separates the previous entry's reads of this buffer from these writes
-                f4* ps = pal_s[flip];
+                f4* ps = pal_s + flip * pcap;
                 flip ^= 1u;
                 if (tid < npieces) ps[tid] = piece[b];
                 if (b < nnb && tid < npieces) piece[b] = pal_g[(size_t)inst_n[b] * rig.J * 6 + joff];  // and the next batch's piece
@@ -1159,7 +1162,8 @@ __device__ __forceinline__ float wave_bounds_packed(const float (&v)[3], bool up
 
 constexpr uint32_t kSkin2Threads = 256;
 
-template <int AR, int K, int LOOK, bool SKIP, bool SPARSE>
+// LONG: tiles with 22 .. kSkin2MaxJoints joints (a wave then moves its palette rows with up to four LDS-DMA instructions instead of two)
+template <int AR, int K, int LOOK, bool SKIP, bool SPARSE, bool LONG>
 __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) void k_skin2(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
     constexpr uint32_t TV = kTileVerts;
@@ -1210,7 +1214,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     const uint32_t pbeg = rig.tile_pair_start[tile];
     const uint32_t np = rig.tile_pair_start[tile + 1] - pbeg;
     const uint32_t jstart = rig.tile_joint_start[tile];
-    const uint32_t jcnt = rig.tile_joint_start[tile + 1] - jstart;  // <= 21
+    const uint32_t jcnt = rig.tile_joint_start[tile + 1] - jstart;  // <= 21 (LONG: <= kSkin2MaxJoints)
 
     // ---------------- block prologue (all 256 threads; no store has been issued yet) ----------------
     for (uint32_t c = tid; c < np; c += kSkin2Threads) pairs_s[c] = rig.pairs[pbeg + c];
@@ -1346,10 +1350,15 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     }
     const uint32_t ninf = (SKINRT_EXP & 8) ? (wave + 1) * K : (SKIP ? wave_influences<K>(w) : 4u * K);
     // palette pieces this lane moves: piece c = (list position c / 6, 16-byte quarter c % 6), c = lane and lane + 64
-    const uint32_t npieces = jcnt * 6;  // <= 126
+    const uint32_t npieces = jcnt * 6;  // <= 126 (LONG: <= 252)
     uint32_t joff0 = 0, joff1 = 0;      // byte offsets inside one instance's palette
     if (lane < npieces) joff0 = (rig.tile_joints[jstart + lane / 6] * 6 + lane % 6) * 16;
     if (lane + 64 < npieces) joff1 = (rig.tile_joints[jstart + (lane + 64) / 6] * 6 + (lane + 64) % 6) * 16;
+    uint32_t joff2 = 0, joff3 = 0;  // (LONG: pieces 128 .. 251)
+    if constexpr (LONG) {
+        if (lane + 128 < npieces) joff2 = (rig.tile_joints[jstart + (lane + 128) / 6] * 6 + (lane + 128) % 6) * 16;
+        if (lane + 192 < npieces) joff3 = (rig.tile_joints[jstart + (lane + 192) / 6] * 6 + (lane + 192) % 6) * 16;
+    }
     const Outputs out{cr.pos, cr.nrm, cr.tan};
     const uint32_t olb = v * 12;
     const bool normalize = plan.normalize != 0;
@@ -1374,6 +1383,12 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
         if (lane + 64 < npieces) {
             const uint32_t lds1 = lds0 + 1024;
             SKINRT_GLDS_AT(joff1, gbase, lds1);
+        }
+        if constexpr (LONG) {
+            if (npieces > 128) {  // wave-uniform.  (More requests per instance only make the counted waits more conservative: they count stores.)
+                if (lane + 128 < npieces) { const uint32_t lds2 = lds0 + 2048; SKINRT_GLDS_AT(joff2, gbase, lds2); }
+                if (lane + 192 < npieces) { const uint32_t lds3 = lds0 + 3072; SKINRT_GLDS_AT(joff3, gbase, lds3); }
+            }
         }
     };
     auto morph_dma = [&](uint32_t hx) {  // request the first (up to) two active pairs of an instance into the slots
@@ -1512,10 +1527,10 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
 // The fix role's kernel.  (Tried: the role inside the k_skin2 launch, its block groups dealt out between the
 // self-staging groups.  Slower — 5.7-6.0 ms against 4.7 on C3: a launch has ONE LDS size, so every fix block takes
 // one of the CU's five 31 KiB block slots from k_skin2; as a kernel of its own it fits into what k_skin2 leaves free.)
-template <int AR, int K, bool SKIP, int BATCH>
+template <int AR, int K, bool SKIP, int BATCH, uint32_t PIECES>
 __global__ __launch_bounds__(256) void k_skin_fix(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
-    fix_role<AR, K, SKIP, BATCH>(rig, cr, plan, smem, blockIdx.x, gridDim.x);
+    fix_role<AR, K, SKIP, BATCH, PIECES>(rig, cr, plan, smem, blockIdx.x, gridDim.x);
 }
 
 // a14: bounds of one instance = min/max over its tiles' partial bounds (order-independent, exact).
@@ -1567,7 +1582,7 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         (uint64_t)plan.ranges_per_chunk * (8 / plan.tile_chunks) < plan.ranges)
         return hipErrorInvalidValue;
     if (plan.v2 && (plan.range2 == 0 || plan.range2 > kSkin2Range || (uint64_t)plan.ranges2 * plan.range2 < cr.I ||
-                    plan.lds_bytes2 > 64 * 1024 || rig.K > 2 || plan.jt2 == 0 || plan.jt2 > 21 || plan.look2 < 1 || plan.look2 > 2 ||
+                    plan.lds_bytes2 > 64 * 1024 || rig.K > 2 || plan.jt2 == 0 || plan.jt2 > kSkin2MaxJoints || (plan.fix_pieces != 128 && plan.fix_pieces != 256) || plan.look2 < 1 || plan.look2 > 2 ||
                     (uint64_t)plan.ranges_per_chunk2 * (8 / plan.tile_chunks) < plan.ranges2 ||
                     plan.run2 == 0 || plan.tiles_per_chunk2 % plan.run2 != 0 || plan.tiles_per_chunk2 < plan.tiles_per_chunk))
         return hipErrorInvalidValue;
@@ -1627,7 +1642,11 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
             // enough lanes that the longest list is a few chunks per block; blocks past a list's end leave at once
             const uint32_t lanes = std::min((cr.I + kFixChunk - 1) / kFixChunk, std::max(1u, conc.fix_blocks / rig.T));
             const dim3 fgrid(8u * ((rig.T + 7) / 8) * lanes), fblock(256);
-#define SKINRT_LAUNCHF(EX, KK, SK, BB) hipLaunchKernelGGL((k_skin_fix<EX, KK, SK, BB>), fgrid, fblock, kFixLdsBytes, fs, rig, cr, plan)
+#define SKINRT_LAUNCHF(EX, KK, SK, BB)                                                                                                     \
+    do {                                                                                                                                   \
+        if (plan.fix_pieces == 128) hipLaunchKernelGGL((k_skin_fix<EX, KK, SK, BB, 128>), fgrid, fblock, fix_lds_bytes(128), fs, rig, cr, plan); \
+        else hipLaunchKernelGGL((k_skin_fix<EX, KK, SK, BB, 256>), fgrid, fblock, fix_lds_bytes(256), fs, rig, cr, plan);                 \
+    } while (0)
 #define SKINRT_LAUNCHFA(KK, SK, BB)                                                        \
     do {                                                                                   \
         if (plan.exact == 1) SKINRT_LAUNCHF(1, KK, SK, BB);                                \
@@ -1651,8 +1670,9 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         const dim3 grid(8u * plan.tiles_per_chunk2 * plan.ranges_per_chunk2), block(kSkin2Threads);
 #define SKINRT_LAUNCH2(EX, KK, LL, SK)                                                                                     \
     do {                                                                                                                   \
-        if (rig.sparse_pairs) hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, true>), grid, block, plan.lds_bytes2, s, rig, cr, plan); \
-        else hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, false>), grid, block, plan.lds_bytes2, s, rig, cr, plan);          \
+        if (plan.jt2 > 21) hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, true, true>), grid, block, plan.lds_bytes2, s, rig, cr, plan); /* long lists: one instantiation for dense and compacted pairs */ \
+        else if (rig.sparse_pairs) hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, true, false>), grid, block, plan.lds_bytes2, s, rig, cr, plan); \
+        else hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, false, false>), grid, block, plan.lds_bytes2, s, rig, cr, plan);   \
     } while (0)
 #define SKINRT_LAUNCH2K(EX, LL)                                                            \
     do {                                                                                   \

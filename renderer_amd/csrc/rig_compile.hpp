@@ -11,6 +11,7 @@ namespace skinrt {
 
 constexpr uint32_t kTileVerts = 256;   // vertices per skinning tile = threads per block
 constexpr uint32_t kTileJointCap = 64; // largest tile-local joint list that is LDS-staged
+constexpr uint32_t kSkin2MaxJoints = 42;  // longest tile joint list the self-staging kernel takes: 252 16-byte palette pieces = four LDS-DMA instructions per wave
 constexpr uint32_t kPalFloats = 24;    // palette entry: 3x4 joint rows, 3x3 normal rows packed, 3 floats of padding
 // Joints farther than this from the origin of their bind space make the skinning sums cancel: a fused and an
 // unfused multiply-add then differ by a few ulp(extent) ~ 2.4e-7 * extent, which at 4 units reaches the
@@ -116,12 +117,12 @@ struct CompiledRig {
     std::vector<uint16_t> lidx;         // [T][4K][256] tile-local joint index (LDS tiles) or global joint id
     std::vector<uint32_t> tile_joint_start;  // [T+1]
     std::vector<uint32_t> tile_joints;       // concatenated tile joint lists (global ids, ascending)
-    std::vector<uint8_t> tile_lds;           // [T] 0 = joint list exceeds kTileJointCap, 1 = fits, 2 = at most 21 joints, 3 = as 2 but
+    std::vector<uint8_t> tile_lds;           // [T] 0 = joint list exceeds kTileJointCap, 1 = fits, 2 = at most kSkin2MaxJoints joints, 3 = as 2 but
                                              // longer than the lists k_skin2's palette ring is sized for: all its instances go to k_skin_fix
     uint32_t tile_kind_count[4] = {0, 0, 0, 0}; // tiles of each kind
     uint32_t max_tile_joints = 0;            // over LDS tiles
     uint32_t max_tile_joints_any = 0;
-    uint32_t max_tile_joints2 = 0;           // over the self-staging kernel's tiles (kind 2): <= 21
+    uint32_t max_tile_joints2 = 0;           // over the self-staging kernel's tiles (kind 2): <= kSkin2MaxJoints
     uint32_t lds_tiles = 0;
     uint64_t extra_set_waves = 0;            // (wave, weight set beyond the first) units of the tiled mesh
     uint64_t skippable_set_waves = 0;        // those whose weights are zero in all 64 lanes, trailing

@@ -1,0 +1,61 @@
+"""Tiles whose joint list has 22 .. 42 entries: served by the self-staging skin kernel's LONG instantiations (four LDS-DMA
+requests per wave and instance) and, for the instances on the work lists, by k_skin_fix with 256-piece staging buffers —
+until round 3 such tiles fell to the loader-wave kernel at 1.5 - 2 x the cost (tools/exp_spread.py).  Bit-equal to the
+fp32 oracle in exact arithmetic, inside 1e-5 rel / 1e-6 abs in the default."""
+import numpy as np
+import pytest
+
+from renderer_amd import synth
+from tests.helpers import assert_close, assert_equal, run_gpu, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _spec(spread, sets, targets, seed):
+    return synth.scaled(synth.tiny_spec(seed=seed), nodes=80, joints=64, verts=1400, sets=sets, targets=targets, target_mode="dense",
+                        joint_spread=spread, clips=2, keys=6, max_depth=10)
+
+
+@pytest.mark.parametrize("spread,sets,targets", [(5, 1, 0), (6, 1, 10), (9, 1, 10), (12, 1, 10), (15, 1, 10), (5, 2, 10), (8, 2, 10), (12, 2, 6)])
+def test_long_joint_lists_bit_equal(oracle32, spread, sets, targets):
+    spec = _spec(spread, sets, targets, seed=300 + spread + sets)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=173)
+    if targets:
+        crowd.morph_weights[:, : targets // 2] = np.float32(0.5)  # several active pairs per tile: the work lists are used
+    got = run_gpu(rig, crowd, exact_arithmetic=1)
+    info = got["info"]
+    assert 21 < info.max_tile_joints <= 42, f"the rig must exercise the long lists: max tile joints {info.max_tile_joints}"
+    assert info.lds_tiles == info.tile_count
+    ref = run_oracle(oracle32, rig, crowd)
+    for k in ("key_index", "world", "palette", "position", "normal", "tangent", "aabb"):
+        assert_equal(got[k], ref[k], f"spread {spread}, {sets} sets, {targets} targets: {k}")
+
+
+def test_long_joint_lists_default_arithmetic(oracle32):
+    spec = _spec(12, 1, 10, seed=341)
+    rig = synth.make_rig(spec)
+    crowd = synth.make_crowd(spec, rig, instances=300)
+    got = run_gpu(rig, crowd)
+    assert got["info"].max_tile_joints > 21
+    ref = run_oracle(oracle32, rig, crowd)
+    for k in ("position", "normal", "tangent"):
+        assert_close(got[k], ref[k], k)
+    assert_equal(got["aabb"][:, 0], got["position"].min(axis=1), "aabb.min")
+    assert_equal(got["aabb"][:, 1], got["position"].max(axis=1), "aabb.max")
+
+
+def test_mixed_short_and_long_tiles_in_one_rig(oracle32):
+    """most tiles short, some long (a second vertex population bound loosely): one ring size serves both"""
+    spec = _spec(3, 1, 8, seed=355)
+    rig = synth.make_rig(spec)
+    rng = np.random.default_rng(9)
+    V = rig.vertex_count
+    loose = slice(V // 2, V // 2 + 300)  # these vertices draw their four joints from a window of 30
+    rig.joints[0][loose] = rng.integers(10, 40, size=(300, 4)).astype(np.uint16)
+    crowd = synth.make_crowd(spec, rig, instances=97)
+    got = run_gpu(rig, crowd, exact_arithmetic=1)
+    assert 21 < got["info"].max_tile_joints <= 42
+    ref = run_oracle(oracle32, rig, crowd)
+    for k in ("position", "normal", "tangent", "aabb"):
+        assert_equal(got[k], ref[k], k)
