@@ -217,7 +217,7 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg, c
         // tail as long as a third of the stage), but ranges long enough to amortise the per-block vertex load
         const uint32_t own = r.tile_kind_count[0] + r.tile_kind_count[1] + (p.v2 ? 0u : r.tile_kind_count[2] + r.tile_kind_count[3]);
         uint64_t range = ((uint64_t)I * std::max<uint32_t>(1, own) + want_blocks - 1) / want_blocks;
-        range = std::min<uint64_t>(std::max<uint64_t>(range, std::max<uint32_t>(p.batch, 32)), 256);  // (the grid spans all tiles: not too many empty blocks)
+        range = std::min<uint64_t>(std::max<uint64_t>(range, std::max<uint32_t>(p.batch, 32)), 256);  // (shorter ranges for few tiles: measured, no gain)
         range = (range + p.batch - 1) / p.batch * p.batch;
         // the kernel's per-block instance-order tables hold 256 entries: never more than that per block
         if (range > 256) range = 256 / p.batch * p.batch;
@@ -431,6 +431,17 @@ int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig**
     UP(chans) UP(clip_chan_count) UP(weight_src) UP(clip_length) UP(times) UP(values) UP(joint_node) UP(ibm) UP(base) UP(wts) UP(lidx)
     UP(tile_joint_start) UP(tile_joints) UP(tile_lds) UP(tile_pair_start) UP(pairs) UP(mblock)
 #undef UP
+    {   // the tiles ordered by kind (RigDev::tile_order)
+        std::vector<uint32_t> order;
+        order.reserve(h.T);
+        for (uint32_t kind = 0; kind < 3; ++kind) {
+            for (uint32_t t = 0; t < h.T; ++t)
+                if (kind < 2 ? h.tile_lds[t] == kind : h.tile_lds[t] >= 2) order.push_back(t);
+            if (kind == 0) d.order_n0 = (uint32_t)order.size();
+            if (kind == 1) d.order_n1 = (uint32_t)order.size() - d.order_n0;
+        }
+        if ((rc = upload(r, order, &d.tile_order)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
+    }
     if ((rc = upload(r, h.default_weights, &defw)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
     r->default_mw = r->bufs.back();
     {

@@ -33,6 +33,8 @@ struct RigDev {
     const uint32_t* tile_joint_start;
     const uint32_t* tile_joints;
     const uint8_t* tile_lds;
+    const uint32_t* tile_order;   // [T] tile indices by kind: kind 0 (order_n0 of them), kind 1 (order_n1), then kinds 2 and 3 — the loader-wave kernel's grid
+    uint32_t order_n0, order_n1;  //     covers ITS tiles only (a grid over all tiles spent 1.9 ms dispatching empty blocks for two real tiles)
     const uint32_t* tile_pair_start;
     const MorphPair* pairs;
     const float* mblock;

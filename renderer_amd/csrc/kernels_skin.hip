@@ -402,7 +402,8 @@ constexpr uint32_t kSkinThreads = 320;  // 4 compute waves (256 vertices) + 1 lo
 // active morph-pair records) into the other LDS buffer and writes batch k-1's bounds.  One
 // LDS-only barrier per batch hands the buffers over.
 template <bool EXACT, int K, bool LDSPAL>
-__global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void k_skin(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
+__global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void k_skin(const RigDev rig, const CrowdDev cr, const SkinPlan plan,
+                                                                                        const uint32_t first, const uint32_t ntiles, const uint32_t tpc) {
     extern __shared__ float4 smem[];
     constexpr uint32_t TV = kTileVerts;
     constexpr int W = 4 * K;
@@ -414,9 +415,11 @@ __global__ __launch_bounds__(kSkinThreads, (K == 1 ? 5 : (K == 2 ? 4 : 2))) void
     // palette rows stay in ONE L2.  Placement is a speed matter only.
     const uint32_t xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
     const uint32_t tc = xcd % plan.tile_chunks, rc = xcd / plan.tile_chunks;
-    const uint32_t tile = tc * plan.tiles_per_chunk + k % plan.tiles_per_chunk;
-    uint32_t rng = rc * plan.ranges_per_chunk + k / plan.tiles_per_chunk;
-    if (tile >= rig.T || rng >= plan.ranges) return;
+    // (the grid covers this launch's OWN tiles: rig.tile_order[first .. first + ntiles), tpc of them per tile chunk)
+    const uint32_t tile_pos = tc * tpc + k % tpc;
+    uint32_t rng = rc * plan.ranges_per_chunk + k / tpc;
+    if (tile_pos >= ntiles || rng >= plan.ranges) return;
+    const uint32_t tile = rig.tile_order[first + tile_pos];
     if (!(SKINRT_RANGE_ORDER & 1)) rng = plan.ranges - 1 - rng;  // last range first: see k_skin2
     // tiles whose joint list fits LDS are skinned by the LDSPAL=true launch, the rest (rare: no
     // joint locality) by the LDSPAL=false launch that gathers the palette from L2
@@ -1559,12 +1562,18 @@ __global__ __launch_bounds__(256) void k_fill_mw(float* mw, const float* default
 
 template <bool EXACT, bool LDSPAL>
 hipError_t launch_skin_k(const RigDev& rig, const CrowdDev& cr, const SkinPlan& plan, hipStream_t s) {
-    const dim3 grid(8u * plan.tiles_per_chunk * plan.ranges_per_chunk), block(kSkinThreads);
+    // this launch's tiles in RigDev::tile_order: the L2-gather form takes kind 0, the LDS-staged form kind 1 — and kinds 2 / 3 where
+    // the self-staging kernel is switched off
+    const uint32_t first = LDSPAL ? rig.order_n0 : 0u;
+    const uint32_t ntiles = LDSPAL ? (plan.v2 ? rig.order_n1 : rig.T - rig.order_n0) : rig.order_n0;
+    if (ntiles == 0) return hipSuccess;
+    const uint32_t tpc = (ntiles + plan.tile_chunks - 1) / plan.tile_chunks;
+    const dim3 grid(8u * tpc * plan.ranges_per_chunk), block(kSkinThreads);
     switch (rig.K) {
-        case 1: hipLaunchKernelGGL((k_skin<EXACT, 1, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
-        case 2: hipLaunchKernelGGL((k_skin<EXACT, 2, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
-        case 3: hipLaunchKernelGGL((k_skin<EXACT, 3, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
-        case 4: hipLaunchKernelGGL((k_skin<EXACT, 4, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan); break;
+        case 1: hipLaunchKernelGGL((k_skin<EXACT, 1, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan, first, ntiles, tpc); break;
+        case 2: hipLaunchKernelGGL((k_skin<EXACT, 2, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan, first, ntiles, tpc); break;
+        case 3: hipLaunchKernelGGL((k_skin<EXACT, 3, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan, first, ntiles, tpc); break;
+        case 4: hipLaunchKernelGGL((k_skin<EXACT, 4, LDSPAL>), grid, block, plan.lds_bytes, s, rig, cr, plan, first, ntiles, tpc); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1608,8 +1617,8 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         // 0.5 ms (C3).  Fork / join by events: the caller's stream sees the stage as one unit.
         // (a tile needs at least 3 pairs to hand an instance over: without such a tile there is no list to build and no
         // k_skin_fix to launch; the active-pair bit rows are k_skin2's own input either way)
-        // The tiles k_skin2 leaves to k_skin (few: long joint lists) go the same way, in front of k_skin_fix on the side
-        // stream, instead of as a tail behind k_skin2.
+        // The tiles k_skin2 leaves to k_skin (few: joint lists over 42 entries) go the same way, in front of k_skin_fix on the
+        // side stream, instead of as a tail behind k_skin2 (in front of k_skin2 on its own stream was measured too: slower).
         const bool lists = cr.fix && (plan.max_pairs > 2 || (plan.kinds & 8u));
         const bool want_fix = lists && !(SKINRT_ABLATE & 32);
         const bool side = (want_fix || others) && conc.side != nullptr && conc.fork != nullptr && conc.join != nullptr;
