@@ -826,7 +826,7 @@ __device__ __forceinline__ void wave_minmax6(float& a0, float& a1, float& a2, fl
 
 // Which of a tile's (tile, target) pairs are active for one instance, and whether the self-staging kernel
 // can morph it.  k_skin2 morphs from its two LDS slots per wave only: an instance with 1 or 2 active pairs — dense or
-// compacted (round 3: a compacted pair's region fits a slot as well) — in a tile with at most 32 pairs.  Every other
+// compacted (round 3: a compacted pair's region fits a slot as well) — in a tile with at most 128 pairs.  Every other
 // non-idle (tile, instance) is "slow": it goes on the tile's work list (k_classify) and is served by the fix role
 // (fix_role).  k_classify and k_skin2's prologue both call this, so they agree on every (tile, instance).
 // (Round 3 also built the alternative for 3 and more active pairs — k_skin2 morphing them itself IN LINE, two pairs at a
@@ -834,8 +834,15 @@ __device__ __forceinline__ void wave_minmax6(float& a0, float& a1, float& a2, fl
 // slower — C3 4.09 -> 4.58 ms, C5 10.6 -> 10.9 ms.  The wait is `vmcnt(0)`, i.e. for every store the wave has in
 // flight, and in a kernel that keeps the HBM write queues full that is many microseconds, which the CU's other waves
 // do not cover; k_skin_fix's waves, running beside k_skin2, have hardly any stores to wait for.  Removed again.)
+// Tiles with 33 .. 128 pairs (round 3; a VRM face: a hundred blend shapes over a few thousand vertices): a 32-bit set
+// cannot name their pairs, but an instance k_skin2 can take has at most two active ones, and two indices can: there
+// `mask` is 0 for an idle instance and else  1 << 31 | second << 8 | first  (second = first for one active pair) —
+// still "equal masks = equal sets", which is all the run sort asks of it.  Until then every non-idle instance of such a
+// tile went on the work lists (tools/exp_face.py with 120 targets: an idle face — three active targets — 5.05 ms
+// against 4.06 with 52 targets).
+constexpr uint32_t kSkin2MaxPairs = 128;  // pairs per tile up to which k_skin2 morphs the instances with one or two active ones itself
 struct PairClass {
-    uint32_t mask;            // bit min(q, 31) = pair q has a non-zero weight
+    uint32_t mask;            // np <= 32: bit q = pair q has a non-zero weight; 33 .. 128 pairs: the encoding above
     bool slow;
     float w_first, w_second;  // weights of the first two active pairs (set for instances with at most two)
 };
@@ -847,17 +854,40 @@ __device__ __forceinline__ PairClass classify_pairs(const MorphPair* pairs, uint
     PairClass pc{0u, false, 0.0f, 0.0f};
     if (np == 0) return pc;  // (rigs without morph targets have no amask at all)
     const uint64_t a0 = active[0];
+    if (np > 32) {  // (block-uniform: np is the tile's)
+        uint32_t count = 0, q1 = 0, q2 = 0;
+        bool compacted = false;
+        for (uint32_t q = 0; q < np; ++q) {
+            const MorphPair mp = pairs[q];
+            const uint32_t t = mp.target;
+            const uint64_t wd = words == 1 ? a0 : active[t >> 6];
+            if ((wd >> (t & 63u)) & 1ull) {
+                if (count == 0) q1 = q2 = q;
+                else if (count == 1) q2 = q;
+                ++count;
+                compacted |= !sparse_ok && !mp.dense;
+            }
+        }
+        if (count == 0 || (SKINRT_ABLATE & 4)) return pc;
+        pc.mask = 0x80000000u | (q2 << 8) | q1;  // (an instance on the lists keeps a non-zero mask too; only its class is looked at)
+        pc.slow = np > kSkin2MaxPairs || count > 2 || compacted;
+        if (!pc.slow) {
+            pc.w_first = mwg[pairs[q1].target];
+            if (count == 2) pc.w_second = mwg[pairs[q2].target];
+        }
+        return pc;
+    }
     uint32_t sparse = 0;
     for (uint32_t q = 0; q < np; ++q) {
         const MorphPair mp = pairs[q];
         const uint32_t t = mp.target;
         const uint64_t wd = words == 1 ? a0 : active[t >> 6];
-        if ((wd >> (t & 63u)) & 1ull) pc.mask |= 1u << min(q, 31u);
-        if (!sparse_ok && !mp.dense) sparse |= 1u << min(q, 31u);
+        if ((wd >> (t & 63u)) & 1ull) pc.mask |= 1u << q;
+        if (!sparse_ok && !mp.dense) sparse |= 1u << q;
     }
-    pc.slow = pc.mask != 0 && (np > 32 || __popc(pc.mask) > 2 || (pc.mask & sparse) != 0);
+    pc.slow = pc.mask != 0 && (__popc(pc.mask) > 2 || (pc.mask & sparse) != 0);
     if (SKINRT_ABLATE & 4) { pc.slow = false; pc.mask = 0; }
-    if (pc.mask != 0 && !pc.slow) {  // at most two active pairs, np <= 32: their weights go into the instance's header
+    if (pc.mask != 0 && !pc.slow) {  // at most two active pairs: their weights go into the instance's header
         const uint32_t q1 = (uint32_t)__ffs((int)pc.mask) - 1;
         pc.w_first = mwg[pairs[q1].target];
         const uint32_t m2 = pc.mask & (pc.mask - 1);
@@ -932,7 +962,7 @@ __global__ __launch_bounds__(256) void k_classify(const RigDev rig, const CrowdD
 }
 
 // fix_role — the (tile, instance) pairs the self-staging role leaves out (k_classify lists them): instances with three or more active
-// morph pairs in the tile, with a compacted pair, or in a tile with more than 32 pairs.  A block
+// morph pairs in the tile, with a compacted pair, or in a tile with more than 128 pairs.  A block
 // takes kFixChunk consecutive work-list entries (k_skin2 blocks append theirs together, so the
 // tile — and with it the block's vertex data — rarely changes inside a chunk).  Per entry the
 // palette rows of the tile's joints are staged in LDS (at most 126 16-byte pieces), the active
@@ -1224,12 +1254,14 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     if (plan.aabb)
         for (uint32_t c = tid; c < kSkin2Range * 6; c += kSkin2Threads) bb_s[c] = -__builtin_inff();  // cells hold {-min, +max}: all folded with max
     __syncthreads();
-    // pairs that move at least one of THIS wave's 64 vertices (bit q, first 32 pairs): the others are
+    // pairs that move at least one of THIS wave's 64 vertices (bit q, first 128 pairs): the others are
     // neither requested nor applied by this wave (their deltas here are all zero)
-    const uint32_t my_pairs = (uint32_t)__ballot(lane < min(np, 32u) && ((pairs_s[min(lane, np ? np - 1 : 0u)].wave_mask >> wave) & 1u));
+    const uint64_t my_pairs_lo = __ballot(lane < np && ((pairs_s[min(lane, np ? np - 1 : 0u)].wave_mask >> wave) & 1u));
+    const uint64_t my_pairs_hi = __ballot(lane + 64 < np && ((pairs_s[min(lane + 64, np ? np - 1 : 0u)].wave_mask >> wave) & 1u));
+    auto mine = [&](uint32_t q) -> bool { return (((q & 64u) ? my_pairs_hi : my_pairs_lo) >> (q & 63u)) & 1ull; };  // q < 128 = kSkin2MaxPairs, wave-uniform
     // active-pair mask of instance-in-range `tid` (bit min(q, 31) = pair q has a non-zero weight) and its class:
     // 0 idle, 1 fast (1 or 2 active pairs: the LDS slots, requested ahead), 3 handed over (3 or more active pairs, or a
-    // tile with more than 32 pairs: on the work list of k_skin_fix already) or padding.  Classes 0 and 1 are this block's.
+    // tile with more than 128 pairs: on the work list of k_skin_fix already) or padding.  Classes 0 and 1 are this block's.
     uint32_t my_mask = 0xffffffffu, my_cls = 3u;
     {
         float w_first = 0.0f, w_second = 0.0f;
@@ -1319,13 +1351,21 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
             fpos = z0 + (nxt - zeros) + sj * sp + within;
             if (within == 0) { pf = 1; m = mask_s[perm_s[nxt]]; }  // describe the next run's pairs
         }
-        const uint32_t na = (uint32_t)__popc(m);  // <= 2
-        uint32_t q1 = 0, q2 = 0;
+        uint32_t na, q1 = 0, q2 = 0;  // na <= 2
+        if (np > 32) {  // PairClass::mask of a tile with 33 .. 128 pairs: the two indices themselves
+            q1 = m & 0xffu;
+            q2 = (m >> 8) & 0xffu;
+            na = m ? (q1 == q2 ? 1u : 2u) : 0u;
+        } else {
+            na = (uint32_t)__popc(m);
+            if (na) {
+                q1 = (uint32_t)__ffs((int)m) - 1;
+                const uint32_t m2 = m & (m - 1);
+                q2 = m2 ? (uint32_t)__ffs((int)m2) - 1 : q1;
+            }
+        }
         float w1 = 0.0f, w2 = 0.0f;
         if (na >= 1) {
-            q1 = (uint32_t)__ffs((int)m) - 1;
-            const uint32_t m2 = m & (m - 1);
-            q2 = m2 ? (uint32_t)__ffs((int)m2) - 1 : q1;
             if (!pf) {
                 const float2 w12 = w12_s[k];
                 w1 = w12.x;
@@ -1400,7 +1440,7 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
         const uint32_t lane_bytes = lane * 16;
         for (uint32_t a = 0; a < ns; ++a) {
             const uint32_t q = (hx >> (16 + 8 * a)) & 0xffu;
-            if (!((my_pairs >> q) & 1u)) continue;
+            if (!mine(q)) continue;
             const MorphPair mp = pairs_s[q];
             const uint32_t doff = __builtin_amdgcn_readfirstlane(mp.data_off);
             const bool dense = __builtin_amdgcn_readfirstlane((uint32_t)mp.dense) != 0;
@@ -1457,8 +1497,8 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
         // (3) morph (a13): p = p0 + sum_m w_m * delta_m, targets ascending
         float p[3] = {p0[0], p0[1], p0[2]}, n[3] = {n0[0], n0[1], n0[2]}, t[3] = {t0[0], t0[1], t0[2]};
         if (na) {
-            if ((my_pairs >> ((hx >> 16) & 0xffu)) & 1u) morph_pair<EXACT>(my_slots, dense1, tid, mw1, p, n, t);
-            if (na >= 2 && ((my_pairs >> (hx >> 24)) & 1u)) morph_pair<EXACT>(my_slots + kMorphWaveFloats, dense2, tid, mw2, p, n, t);
+            if (mine((hx >> 16) & 0xffu)) morph_pair<EXACT>(my_slots, dense1, tid, mw1, p, n, t);
+            if (na >= 2 && mine(hx >> 24)) morph_pair<EXACT>(my_slots + kMorphWaveFloats, dense2, tid, mw2, p, n, t);
         }
         // (4) position
         float op[3];

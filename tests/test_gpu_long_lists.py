@@ -59,3 +59,32 @@ def test_mixed_short_and_long_tiles_in_one_rig(oracle32):
     ref = run_oracle(oracle32, rig, crowd)
     for k in ("position", "normal", "tangent", "aabb"):
         assert_equal(got[k], ref[k], k)
+
+
+@pytest.mark.parametrize("targets,active", [(40, 1), (48, 2), (64, 2), (48, 5), (70, 2), (128, 2), (140, 2)])
+def test_tiles_with_more_than_32_morph_pairs(oracle32, targets, active):
+    """dense targets over the whole (small) mesh: every tile carries `targets` pairs.  Instances with one or two active targets are
+    morphed by the self-staging kernel itself up to 128 pairs per tile (pair-encoded masks), the rest go through the work lists;
+    either way the oracle's bits."""
+    spec = synth.scaled(synth.tiny_spec(seed=500 + targets), nodes=30, joints=24, verts=1100, targets=targets, target_mode="dense",
+                        target_frac=1.0, clips=1, keys=4)
+    rig = synth.make_rig(spec)
+    I = 211
+    crowd = synth.make_crowd(spec, rig, instances=I)
+    rng = np.random.default_rng(targets * 7 + active)
+    w = np.zeros((I, targets), np.float32)
+    for i in range(I):
+        k = active if i % 5 else (0 if i % 10 else active + 2)  # mostly `active` targets, some idle instances, some with more
+        if k:
+            w[i, rng.choice(targets, size=k, replace=False)] = rng.uniform(0.1, 1.0, size=k).astype(np.float32)
+    crowd.morph_weights[:] = w
+    got = run_gpu(rig, crowd, exact_arithmetic=1)
+    ref = run_oracle(oracle32, rig, crowd)
+    for k in ("position", "normal", "tangent", "aabb"):
+        assert_equal(got[k], ref[k], f"{targets} targets, {active} active: {k}")
+    # a second frame with other weights on the same crowd shape (runs, spacers and lists change)
+    crowd.morph_weights[:] = np.roll(w, 3, axis=0)
+    got = run_gpu(rig, crowd, exact_arithmetic=1)
+    ref = run_oracle(oracle32, rig, crowd)
+    for k in ("position", "normal", "tangent"):
+        assert_equal(got[k], ref[k], f"{targets} targets, {active} active, rolled: {k}")

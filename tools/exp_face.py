@@ -13,13 +13,14 @@ from renderer_amd import abi, api, synth
 from renderer_amd.abi import MorphTarget
 
 I = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+NT = int(os.environ.get("FACE_TARGETS", "52"))  # (more than ~80: face tiles exceed 32 pairs, the limit of k_skin2's per-instance masks)
 spec = synth.scaled(synth.CONFIGS["c3"], targets=0)
 rig = synth.make_rig(spec)
 V = rig.vertex_count
 rng = np.random.default_rng(5)
 face = int(0.15 * V)
 targets = []
-for m in range(52):
+for m in range(NT):
     cnt = int(V * rng.uniform(0.02, 0.10))
     start = int(rng.integers(0, face - cnt))
     dp = np.zeros((V, 3), np.float32); dn = np.zeros((V, 3), np.float32); dt = np.zeros((V, 4), np.float32)
@@ -28,18 +29,18 @@ for m in range(52):
     dt[start:start + cnt, :3] = rng.normal(scale=0.05, size=(cnt, 3))
     targets.append(MorphTarget(position=dp, normal=dn, tangent=dt))
 rig.targets = targets
-rig.default_weights = np.zeros(52, np.float32)
+rig.default_weights = np.zeros(NT, np.float32)
 crowd = synth.make_crowd(spec, rig, instances=I)
 patterns = {}
-w = rng.uniform(0, 1, size=(I, 52)).astype(np.float32)
-w[rng.uniform(size=(I, 52)) < 0.75] = 0
+w = rng.uniform(0, 1, size=(I, NT)).astype(np.float32)
+w[rng.uniform(size=(I, NT)) < 0.75] = 0
 patterns["benchmark-like (25 % non-zero)"] = w
-w = np.zeros((I, 52), np.float32)
+w = np.zeros((I, NT), np.float32)
 for k in range(3):
-    w[np.arange(I), rng.integers(0, 52, size=I)] = rng.uniform(0.1, 1, size=I).astype(np.float32)
+    w[np.arange(I), rng.integers(0, NT, size=I)] = rng.uniform(0.1, 1, size=I).astype(np.float32)
 patterns["idle face (3 active)"] = w
-patterns["face tracking (all 52 active)"] = rng.uniform(0.01, 1, size=(I, 52)).astype(np.float32)
-patterns["no morphing (all zero)"] = np.zeros((I, 52), np.float32)
+patterns["face tracking (all 52 active)"] = rng.uniform(0.01, 1, size=(I, NT)).astype(np.float32)
+patterns["no morphing (all zero)"] = np.zeros((I, NT), np.float32)
 with api.Context() as ctx:
     r = api.Rig(ctx, rig)
     info = r.info
