@@ -193,7 +193,10 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg, c
         p.jt2 = std::max<uint32_t>(1, std::min<uint32_t>(r.max_tile_joints2, kSkin2MaxJoints));
         p.fix_pieces = 128;
         for (uint32_t t = 0; t < r.T; ++t)
-            if (r.tile_lds[t] >= 2 && (r.tile_joint_start[t + 1] - r.tile_joint_start[t]) * 6 > 128) { p.fix_pieces = 256; break; }
+            if (r.tile_lds[t] >= 2) {
+                const uint32_t pieces = (r.tile_joint_start[t + 1] - r.tile_joint_start[t]) * 6;
+                p.fix_pieces = std::max<uint32_t>(p.fix_pieces, pieces > 256 ? 384 : (pieces > 128 ? 256 : 128));
+            }
         auto lds_for = [&](uint32_t look) { return skin2_lds_bytes(p.jt2, look, r.M != 0, p.max_pairs); };
         // blocks per CU the LDS allows; two instances of lookahead unless one buys another resident block
         auto blocks_for = [&](uint32_t look) { return skin2_blocks_per_cu(lds_for(look)); };

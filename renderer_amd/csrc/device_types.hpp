@@ -94,7 +94,7 @@ struct SkinPlan {
     uint32_t lds_bytes2;         // dynamic LDS per k_skin2 block
     uint32_t kinds;              // bit k set: the rig has tiles of kind k
     uint32_t jt2;                // k_skin2: joints per palette slot = longest joint list among its tiles (<= kSkin2MaxJoints)
-    uint32_t fix_pieces;         // k_skin_fix: 16-byte palette pieces its staging buffers hold (128, or 256 where a tile of kind 2 / 3 has more than 21 joints)
+    uint32_t fix_pieces;         // k_skin_fix: 16-byte palette pieces its staging buffers hold (128; 256 where a tile of kind 2 / 3 has more than 21 joints, 384 where more than 42)
     uint32_t run2;               // k_skin2: an XCD's tiles come in runs of run2 consecutive tiles, the runs dealt round-robin over
                                  // the tile chunks (1: fully interleaved; tiles_per_chunk2: one contiguous chunk per XCD)
     uint32_t tiles_per_chunk2;   // tiles_per_chunk rounded up to whole runs

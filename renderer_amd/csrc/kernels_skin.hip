@@ -993,7 +993,7 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
     constexpr bool EXACT = AR != 0, NEXACT = AR == 1;  // AR 2: positions contraction-free, normals / tangents fused
     constexpr uint32_t kFixBatch = SKINRT_FIX_BATCH ? SKINRT_FIX_BATCH : (uint32_t)BATCH;
     static_assert(kFixChunk % kFixBatch == 0, "a chunk is a whole number of batches");
-    constexpr uint32_t pcap = PIECES;                                                     // 128 or 256 (= plan.fix_pieces)
+    constexpr uint32_t pcap = PIECES;                                                     // 128, 256 or 384 (= plan.fix_pieces)
     f4* pal_s = reinterpret_cast<f4*>(smem);                                             // [2][pcap]
     float (*part)[6] = reinterpret_cast<float (*)[6]>(pal_s + 2 * pcap);                 // [4][6] (+ 32 B pad)
     MorphPair* pairs_l = reinterpret_cast<MorphPair*>(reinterpret_cast<char*>(part) + 4 * 6 * 4 + 32);  // the tile's first 64 pair records
@@ -1029,6 +1029,8 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
     const uint32_t jstart = rig.tile_joint_start[tile];
     const uint32_t npieces = (rig.tile_joint_start[tile + 1] - jstart) * 6;  // <= plan.fix_pieces (<= 256 = the block's threads) for k_skin2's tiles
     const uint32_t joff = tid < npieces ? rig.tile_joints[jstart + tid / 6] * 6 + tid % 6 : 0u;
+    // (PIECES = 384: tiles of 43 .. 64 joints handed over whole — threads 0 .. 127 move a second piece, tid + 256)
+    const uint32_t joff2 = (PIECES > 256 && tid + 256 < npieces) ? rig.tile_joints[jstart + (tid + 256) / 6] * 6 + (tid + 256) % 6 : 0u;
     const uint32_t pbeg = rig.tile_pair_start[tile], pend = rig.tile_pair_start[tile + 1];
     if (tid < min(pend - pbeg, 64u)) pairs_l[tid] = rig.pairs[pbeg + tid];
     __syncthreads();
@@ -1050,6 +1052,7 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
     if (e0 + lane < count && lane < kFixChunk) ents = list[kListStep * (int)(e0 + lane)];
     uint32_t inst[kFixBatch];
     f4 piece[kFixBatch];
+    f4 piece2[PIECES > 256 ? kFixBatch : 1];
     float mwq[kFixBatch];  // lane q: weight of pair q (first 64 pairs) for instance b; 0 for b past the batch's end
     {
         const uint32_t nb0 = min(kFixBatch, min(count, e0 + kFixChunk) - e0);
@@ -1058,6 +1061,7 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
             inst[b] = __builtin_amdgcn_readlane(ents, b < nb0 ? b : 0u);
             piece[b] = f4{0.0f, 0.0f, 0.0f, 0.0f};
             if (b < nb0 && tid < npieces) piece[b] = pal_g[(size_t)inst[b] * rig.J * 6 + joff];
+            if constexpr (PIECES > 256) { if (b < nb0 && tid + 256 < npieces) piece2[b] = pal_g[(size_t)inst[b] * rig.J * 6 + joff2]; }
             mwq[b] = (b < nb0 && lane < np64) ? cr.mw[(size_t)inst[b] * M + pairs_l[lane].target] : 0.0f;
         }
     }
@@ -1129,6 +1133,10 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
                 flip ^= 1u;
                 if (tid < npieces) ps[tid] = piece[b];
                 if (b < nnb && tid < npieces) piece[b] = pal_g[(size_t)inst_n[b] * rig.J * 6 + joff];  // and the next batch's piece
+                if constexpr (PIECES > 256) {
+                    if (tid + 256 < npieces) ps[tid + 256] = piece2[b];
+                    if (b < nnb && tid + 256 < npieces) piece2[b] = pal_g[(size_t)inst_n[b] * rig.J * 6 + joff2];
+                }
                 lds_barrier();  // LDS only: __syncthreads() would also wait for this wave's stores
                 float op[3];
                 skin_store<EXACT, NEXACT, K, SKIP>(LdsPal{ps}, w, li, ninf, p[b], n[b], t[b], normalize, valid && !(SKINRT_FIX_ABLATE & 2), out,
@@ -1153,6 +1161,7 @@ __device__ __forceinline__ void fix_role(const RigDev& rig, const CrowdDev& cr, 
 #pragma unroll
             for (uint32_t b = 0; b < kFixBatch; ++b) {
                 if (b >= nb && b < nnb && tid < npieces) piece[b] = pal_g[(size_t)inst_n[b] * rig.J * 6 + joff];
+                if constexpr (PIECES > 256) { if (b >= nb && b < nnb && tid + 256 < npieces) piece2[b] = pal_g[(size_t)inst_n[b] * rig.J * 6 + joff2]; }
                 inst[b] = inst_n[b];
             }
         }
@@ -1631,7 +1640,7 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         (uint64_t)plan.ranges_per_chunk * (8 / plan.tile_chunks) < plan.ranges)
         return hipErrorInvalidValue;
     if (plan.v2 && (plan.range2 == 0 || plan.range2 > kSkin2Range || (uint64_t)plan.ranges2 * plan.range2 < cr.I ||
-                    plan.lds_bytes2 > 64 * 1024 || rig.K > 2 || plan.jt2 == 0 || plan.jt2 > kSkin2MaxJoints || (plan.fix_pieces != 128 && plan.fix_pieces != 256) || plan.look2 < 1 || plan.look2 > 2 ||
+                    plan.lds_bytes2 > 64 * 1024 || rig.K > 2 || plan.jt2 == 0 || plan.jt2 > kSkin2MaxJoints || (plan.fix_pieces != 128 && plan.fix_pieces != 256 && plan.fix_pieces != 384) || plan.look2 < 1 || plan.look2 > 2 ||
                     (uint64_t)plan.ranges_per_chunk2 * (8 / plan.tile_chunks) < plan.ranges2 ||
                     plan.run2 == 0 || plan.tiles_per_chunk2 % plan.run2 != 0 || plan.tiles_per_chunk2 < plan.tiles_per_chunk))
         return hipErrorInvalidValue;
@@ -1694,7 +1703,8 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
 #define SKINRT_LAUNCHF(EX, KK, SK, BB)                                                                                                     \
     do {                                                                                                                                   \
         if (plan.fix_pieces == 128) hipLaunchKernelGGL((k_skin_fix<EX, KK, SK, BB, 128>), fgrid, fblock, fix_lds_bytes(128), fs, rig, cr, plan); \
-        else hipLaunchKernelGGL((k_skin_fix<EX, KK, SK, BB, 256>), fgrid, fblock, fix_lds_bytes(256), fs, rig, cr, plan);                 \
+        else if (plan.fix_pieces == 256) hipLaunchKernelGGL((k_skin_fix<EX, KK, SK, BB, 256>), fgrid, fblock, fix_lds_bytes(256), fs, rig, cr, plan); \
+        else hipLaunchKernelGGL((k_skin_fix<EX, KK, SK, BB, 384>), fgrid, fblock, fix_lds_bytes(384), fs, rig, cr, plan);                 \
     } while (0)
 #define SKINRT_LAUNCHFA(KK, SK, BB)                                                        \
     do {                                                                                   \

@@ -522,6 +522,15 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
     // k_skin_fix (kind 3: every instance of the tile goes on its work list; that kernel stages any list of up to 42
     // joints and runs beside k_skin2 in what k_skin2 leaves free) buys one, do it.
     // (C3's avatar cut into three skins: lists of 8 except three straddling tiles with 15; 4 -> 5 blocks per CU.)
+    // The same for the few tiles whose lists are too long for k_skin2 altogether (43 .. 64 joints: kind 1, the loader-wave
+    // kernel — which, for a handful of tiles, is a 0.8 ms tail of one-instance batches behind k_skin2): where they are at
+    // most 2 % of the tiles they go to k_skin_fix whole as well (it stages up to 384 palette pieces on such rigs).
+    if (K <= 2 && r.tile_kind_count[2] > 0 && r.tile_kind_count[1] > 0 && (uint64_t)r.tile_kind_count[1] * 50 <= T) {
+        for (uint32_t t = 0; t < T; ++t)
+            if (r.tile_lds[t] == 1) r.tile_lds[t] = 3;
+        r.tile_kind_count[3] += r.tile_kind_count[1];
+        r.tile_kind_count[1] = 0;
+    }
     if (K <= 2 && r.tile_kind_count[2] > 0) {
         uint32_t hist[kSkin2MaxJoints + 1] = {0};
         for (uint32_t t = 0; t < T; ++t)

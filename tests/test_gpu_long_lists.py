@@ -88,3 +88,24 @@ def test_tiles_with_more_than_32_morph_pairs(oracle32, targets, active):
     ref = run_oracle(oracle32, rig, crowd)
     for k in ("position", "normal", "tangent"):
         assert_equal(got[k], ref[k], f"{targets} targets, {active} active, rolled: {k}")
+
+
+@pytest.mark.parametrize("sets,targets", [(1, 0), (1, 9), (2, 6)])
+def test_few_tiles_over_42_joints_are_handed_over_whole(oracle32, sets, targets):
+    """one tile of a 60-tile mesh bound to a window of 60 bones (43 .. 64 joints: too long for the self-staging kernel): at most 2 % of
+    the tiles, so it goes to k_skin_fix whole (384-piece staging) instead of the loader-wave kernel.  The oracle's bits."""
+    spec = synth.scaled(synth.tiny_spec(seed=611 + sets + targets), nodes=90, joints=80, verts=60 * 256, sets=sets, targets=targets,
+                        target_mode="dense", joint_spread=2, clips=2, keys=5, max_depth=10)
+    rig = synth.make_rig(spec)
+    rng = np.random.default_rng(23)
+    v0 = 31 * 256
+    for k in range(sets):
+        rig.joints[k][v0:v0 + 256] = rng.integers(5, 65, size=(256, 4)).astype(np.uint16)
+    crowd = synth.make_crowd(spec, rig, instances=41)
+    got = run_gpu(rig, crowd, exact_arithmetic=1)
+    info = got["info"]
+    assert 42 < info.max_tile_joints <= 64, info.max_tile_joints
+    assert info.handed_over_tiles >= 1
+    ref = run_oracle(oracle32, rig, crowd)
+    for k in ("position", "normal", "tangent", "aabb"):
+        assert_equal(got[k], ref[k], f"{sets} sets, {targets} targets: {k}")
