@@ -267,9 +267,10 @@ typedef struct skinrt_rig_info {
     /* ABI 6.  The palette holds every skin's joints one skin after the other, then one entry per distinct node of an
      * un-skinned section (joint matrix = the node's world matrix): palette_count = sum of joint counts + those. */
     uint32_t skin_count, section_count, palette_count;
-    /* tiles (of tile_count) whose joint list is longer than the lists the main skin kernel's LDS ring is sized for: at
-     * most 2 % of the tiles, served whole by the kernel that otherwise takes the instances with many active morph
-     * pairs (typically the tiles that straddle two mesh sections with different skins) */
+    /* tiles (of tile_count) whose joint list is longer than the lists the main skin kernel's LDS ring is sized for (at
+     * most 2 % of the tiles: typically those that straddle two mesh sections with different skins) or longer than it
+     * takes at all (43 .. 64 joints; again at most 2 %): served whole by the kernel that otherwise takes the instances
+     * with many active morph pairs */
     uint32_t handed_over_tiles;
 } skinrt_rig_info;
 
