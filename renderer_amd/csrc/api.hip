@@ -203,6 +203,13 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg, c
         p.look2 = blocks_for(1) > blocks_for(2) ? 1 : 2;
         p.lds_bytes2 = lds_for(p.look2) + (uint32_t)env.lds_pad;
         if (p.lds_bytes2 > 64 * 1024) p.v2 = 0;
+        if (r.split_joints && p.v2) {  // the short class's ring
+            p.split2 = 1;
+            p.jt2s = std::max<uint32_t>(1, r.split_joints_short);
+            auto lds_s = [&](uint32_t look) { return skin2_lds_bytes(p.jt2s, look, r.M != 0, p.max_pairs); };
+            p.look2s = skin2_blocks_per_cu(lds_s(1)) > skin2_blocks_per_cu(lds_s(2)) ? 1 : 2;
+            p.lds_bytes2s = lds_s(p.look2s) + (uint32_t)env.lds_pad;
+        }
         uint64_t r2 = ((uint64_t)I * std::max<uint32_t>(1, r.T) + want_blocks - 1) / want_blocks;
         p.range2 = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(r2, 1), kSkin2Range);
         if (env.range2 > 0) p.range2 = std::min<uint32_t>(kSkin2Range, (uint32_t)env.range2);
@@ -444,6 +451,16 @@ int skinrt_upload_rig(skinrt_ctx* ctx, const skinrt_rig_desc* desc, skinrt_rig**
             if (kind == 1) d.order_n1 = (uint32_t)order.size() - d.order_n0;
         }
         if ((rc = upload(r, order, &d.tile_order)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
+        std::vector<uint32_t> order2;
+        if (h.split_joints) {
+            for (int pass = 0; pass < 2; ++pass) {
+                for (uint32_t t = 0; t < h.T; ++t)
+                    if (h.tile_lds[t] == 2 && ((h.tile_joint_start[t + 1] - h.tile_joint_start[t] <= h.split_joints) == (pass == 0))) order2.push_back(t);
+                if (pass == 0) d.order2_short = (uint32_t)order2.size();
+            }
+            d.order2_long = (uint32_t)order2.size() - d.order2_short;
+        }
+        if ((rc = upload(r, order2, &d.tile_order2)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
     }
     if ((rc = upload(r, h.default_weights, &defw)) != SKINRT_OK) { skinrt_destroy_rig(r); return rc; }
     r->default_mw = r->bufs.back();

@@ -34,6 +34,8 @@ struct RigDev {
     const uint32_t* tile_joints;
     const uint8_t* tile_lds;
     const uint32_t* tile_order;   // [T] tile indices by kind: kind 0 (order_n0 of them), kind 1 (order_n1), then kinds 2 and 3 — the loader-wave kernel's grid
+    const uint32_t* tile_order2;  // CompiledRig::split_joints != 0: the kind-2 tiles, short lists first (order2_short of them), then the long ones (order2_long)
+    uint32_t order2_short, order2_long;
     uint32_t order_n0, order_n1;  //     covers ITS tiles only (a grid over all tiles spent 1.9 ms dispatching empty blocks for two real tiles)
     const uint32_t* tile_pair_start;
     const MorphPair* pairs;
@@ -99,6 +101,11 @@ struct SkinPlan {
                                  // the tile chunks (1: fully interleaved; tiles_per_chunk2: one contiguous chunk per XCD)
     uint32_t tiles_per_chunk2;   // tiles_per_chunk rounded up to whole runs
     uint32_t look2;              // k_skin2: palette LDS-DMA runs this many instances ahead (1 or 2); ring = look2 + 1 slots
+    // k_skin2 as two launches (split2 != 0; CompiledRig::split_joints): jt2 / look2 / lds_bytes2 above are the LONG class's (and the
+    // whole kernel's where there is no split), these the short class's; list2_n != 0: the launch covers rig.tile_order2[list2_first ..
+    // + list2_n) instead of all tiles (set per launch by launch_skin)
+    uint32_t split2, jt2s, look2s, lds_bytes2s;
+    uint32_t list2_first, list2_n;
 };
 
 // Side stream + fork / join events for the part of the skin stage that runs next to k_skin2 (k_skin_fix);

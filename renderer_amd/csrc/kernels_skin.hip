@@ -1221,8 +1221,12 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     // palette is too large for one L2 and neighbouring tiles sharing joints matters more (C5: +1 % interleaved)
     // (plan.run2 = tiles per run: 1 = fully interleaved, tiles_per_chunk2 = one contiguous chunk per XCD)
     const uint32_t jt = kblk % plan.tiles_per_chunk2;
-    const uint32_t tile = ((jt / plan.run2) * plan.tile_chunks + tc) * plan.run2 + jt % plan.run2;
+    uint32_t tile = ((jt / plan.run2) * plan.tile_chunks + tc) * plan.run2 + jt % plan.run2;
     uint32_t rng = rc * plan.ranges_per_chunk2 + kblk / plan.tiles_per_chunk2;
+    if (plan.list2_n) {  // one of two launches (SkinPlan::split2): the position just computed indexes this launch's tiles
+        if (tile >= plan.list2_n || rng >= plan.ranges2) return;
+        tile = rig.tile_order2[plan.list2_first + tile];
+    }
     if (tile >= rig.T || rng >= plan.ranges2) return;
     if (rig.tile_lds[tile] != 2) return;  // other tiles: k_skin
     // The grid walks the instance ranges from the LAST to the first.  The pose stage has just written the palettes in
@@ -1726,6 +1730,8 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         };
         const bool beside = want_fix || (side && others);
         if (beside && !conc.skin2_first && (e = launch_fix()) != hipSuccess) return e;
+        const SkinPlan& whole_plan = plan;
+        auto launch2 = [&](const SkinPlan& plan) -> hipError_t {  // (`plan`: this launch's — the macros below name it)
         const dim3 grid(8u * plan.tiles_per_chunk2 * plan.ranges_per_chunk2), block(kSkin2Threads);
 #define SKINRT_LAUNCH2(EX, KK, LL, SK)                                                                                     \
     do {                                                                                                                   \
@@ -1743,7 +1749,24 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         else { if (plan.exact == 1) SKINRT_LAUNCH2K(1, 2); else if (plan.exact == 2) SKINRT_LAUNCH2K(2, 2); else SKINRT_LAUNCH2K(0, 2); }
 #undef SKINRT_LAUNCH2K
 #undef SKINRT_LAUNCH2
-        e = hipGetLastError();
+        return hipGetLastError();
+        };
+        if (!whole_plan.split2) e = launch2(whole_plan);
+        else {
+            // two launches, each over its own tiles with the ring its class needs; the long lists first (fewer, slower blocks:
+            // not the ones to end the stage with)
+            for (int cls = 1; cls >= 0 && e == hipSuccess; --cls) {
+                SkinPlan pc = whole_plan;
+                pc.list2_first = cls ? rig.order2_short : 0u;
+                pc.list2_n = cls ? rig.order2_long : rig.order2_short;
+                if (pc.list2_n == 0) continue;
+                if (!cls) { pc.jt2 = whole_plan.jt2s; pc.look2 = whole_plan.look2s; pc.lds_bytes2 = whole_plan.lds_bytes2s; }
+                const uint32_t tpc = (pc.list2_n + pc.tile_chunks - 1) / pc.tile_chunks;
+                pc.run2 = std::min<uint32_t>(pc.run2, std::max<uint32_t>(1u, tpc));
+                pc.tiles_per_chunk2 = (tpc + pc.run2 - 1) / pc.run2 * pc.run2;
+                e = launch2(pc);
+            }
+        }
         if (e == hipSuccess && beside && conc.skin2_first) e = launch_fix();
         if (side && beside) {  // join even after a failed launch: the side stream's work may already be enqueued
             const hipError_t je = hipStreamWaitEvent(s, conc.join, 0);

@@ -560,6 +560,38 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
             r.tile_kind_count[2] -= moved;
             r.tile_kind_count[3] += moved;
         }
+        // What is left may still be a mixed lot — most tiles with short lists, more than 2 % with long ones (hands, hair, a
+        // collar) — and one ring size for all of them costs the short tiles the long tiles' LDS (C3's avatar with a tenth of its
+        // tiles on 36 joints: 4.70 ms against 4.03).  Then k_skin2 runs as two launches, each with the ring its class needs.
+        // The cut is chosen with the measured cost of a ring size (tools/exp_spread.py: the stage against joints per tile,
+        // i.e. against resident blocks and lookahead), and taken only where it promises 3 % of the stage.
+        {
+            auto cost = [&](uint32_t jt) {
+                switch (blocks(jt)) {  // 2 * blocks per CU (+ 1 with two instances of lookahead)
+                    case 15: case 14: case 13: case 12: case 11: return 1.00;
+                    case 10: return 1.03;
+                    case 9: return 1.04;
+                    case 8: return 1.12;
+                    case 7: return 1.20;
+                    case 6: return 1.30;
+                    default: return 1.50;
+                }
+            };
+            uint32_t h2[kSkin2MaxJoints + 1] = {0};
+            for (uint32_t t = 0; t < T; ++t)
+                if (r.tile_lds[t] == 2) h2[r.tile_joint_start[t + 1] - r.tile_joint_start[t]] += 1;
+            const uint32_t full2 = r.max_tile_joints2, n2 = r.tile_kind_count[2];
+            const double whole = (double)n2 * cost(full2);
+            double best = whole * 0.97;
+            uint32_t below = 0, longest = 0;
+            for (uint32_t c = 1; c < full2; ++c) {
+                below += h2[c];
+                if (h2[c]) longest = c;
+                if (below == 0 || below == n2 || !h2[c]) continue;
+                const double split = (double)below * cost(longest) + (double)(n2 - below) * cost(full2) + 0.005 * n2;  // (a second launch's tail)
+                if (split < best) { best = split; r.split_joints = c; r.split_joints_short = longest; }
+            }
+        }
     }
 }
 

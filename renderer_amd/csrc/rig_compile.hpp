@@ -123,6 +123,10 @@ struct CompiledRig {
     uint32_t max_tile_joints = 0;            // over LDS tiles
     uint32_t max_tile_joints_any = 0;
     uint32_t max_tile_joints2 = 0;           // over the self-staging kernel's tiles (kind 2): <= kSkin2MaxJoints
+    // k_skin2 in two launches (0: one): kind-2 tiles with at most split_joints joints run with a palette ring sized for them
+    // (split_joints_short = their longest list), the longer ones with the ring of max_tile_joints2 — a rig of mostly short
+    // lists does not pay the long ones' LDS on every tile
+    uint32_t split_joints = 0, split_joints_short = 0;
     uint32_t lds_tiles = 0;
     uint64_t extra_set_waves = 0;            // (wave, weight set beyond the first) units of the tiled mesh
     uint64_t skippable_set_waves = 0;        // those whose weights are zero in all 64 lanes, trailing

@@ -136,6 +136,48 @@ int main() {
         CHECK(compile_rig(&rig.desc, nullptr, c, why) == SKINRT_OK);
         CHECK(c.promoted_pairs == 0 && c.pairs.empty());
     }
+    // ring classes: 40 tiles, 34 of them on 4 joints, 6 on a window of 30 -> k_skin2 in two launches, cut between the two lengths;
+    // all tiles alike -> one launch
+    for (int mixed = 1; mixed >= 0; --mixed) {
+        const uint32_t J = 40, tiles = 40, V = tiles * kTileVerts;
+        std::vector<int32_t> parent(J, -1);
+        std::vector<float> t(J * 3, 0.0f), rq(J * 4, 0.0f), sc(J * 3, 1.0f);
+        for (uint32_t n = 0; n < J; ++n) rq[n * 4 + 3] = 1.0f;
+        std::vector<uint32_t> jn(J);
+        for (uint32_t n = 0; n < J; ++n) jn[n] = n;
+        std::vector<float> pos(V * 3, 0.5f), nrm(V * 3, 0.0f), tan(V * 3, 0.0f), w(V * 4, 0.25f);
+        std::vector<uint16_t> j(V * 4);
+        for (uint32_t v = 0; v < V; ++v) {
+            const uint32_t tile = v / kTileVerts;
+            const bool lng = mixed && tile % 7 == 3;  // tiles 3, 10, 17, 24, 31, 38
+            for (int a = 0; a < 4; ++a) j[v * 4 + a] = (uint16_t)(lng ? (v * 7 + a * 11) % 30 : (tile % 9) + a);
+        }
+        const uint16_t* jp[1] = {j.data()};
+        const float* wp[1] = {w.data()};
+        skinrt_rig_desc d{};
+        d.struct_size = sizeof(d);
+        d.node_count = J; d.parent = parent.data(); d.translation = t.data(); d.rotation = rq.data(); d.scale = sc.data();
+        d.joint_count = J; d.joint_node = jn.data();
+        d.vertex_count = V; d.position = pos.data(); d.normal = nrm.data(); d.tangent = tan.data(); d.tangent_stride = 3;
+        d.set_count = 1; d.joints = jp; d.weights = wp;
+        // (one morph target, so that the blocks carry morph slots: without them even 30-joint rings leave four blocks per CU
+        // and the cut would not pay)
+        std::vector<uint32_t> touched = run(0, kTileVerts);
+        std::vector<float> dp(kTileVerts * 3, 0.125f);
+        skinrt_morph_target_desc tg{kTileVerts, touched.data(), dp.data(), nullptr, nullptr};
+        d.target_count = 1; d.targets = &tg;
+        CompiledRig c;
+        CHECK(compile_rig(&d, nullptr, c, why) == SKINRT_OK);
+        if (mixed) {
+            CHECK(c.max_tile_joints2 == 30);
+            CHECK(c.split_joints >= 4 && c.split_joints < 30);
+            CHECK(c.split_joints_short == 4);
+            CHECK(c.tile_kind_count[2] == tiles);
+        } else {
+            CHECK(c.max_tile_joints2 == 4);
+            CHECK(c.split_joints == 0);
+        }
+    }
     if (failures) { std::printf("rig compiler selftest: %d check(s) failed (%s)\n", failures, why.c_str()); return 1; }
     std::printf("rig compiler selftest ok\n");
     return 0;
