@@ -111,7 +111,7 @@ typedef struct skinrt_config {
      *    (sample / lane-per-instance propagate / palette) used for very deep or large rigs. */
     uint32_t pose_path;
     /* 0: choose per tile; 1: only the loader-wave skinning kernel (the self-staging kernel, used
-     *    for tiles with at most 42 joints and rigs with at most 2 weight sets, is switched off). */
+     *    for tiles with at most 64 joints and rigs with at most 2 weight sets, is switched off). */
     uint32_t skin_path;
     /* Where skinrt_create_crowd puts the position / normal / tangent arrays of a large crowd
      * (3 arrays >= 1 GiB together).  0: one array per third of the device's physical HBM address
@@ -268,8 +268,7 @@ typedef struct skinrt_rig_info {
      * un-skinned section (joint matrix = the node's world matrix): palette_count = sum of joint counts + those. */
     uint32_t skin_count, section_count, palette_count;
     /* tiles (of tile_count) whose joint list is longer than the lists the main skin kernel's LDS ring is sized for (at
-     * most 2 % of the tiles: typically those that straddle two mesh sections with different skins) or longer than it
-     * takes at all (43 .. 64 joints; again at most 2 %): served whole by the kernel that otherwise takes the instances
+     * most 2 % of the tiles: typically those that straddle two mesh sections with different skins): served whole by the kernel that otherwise takes the instances
      * with many active morph pairs */
     uint32_t handed_over_tiles;
 } skinrt_rig_info;

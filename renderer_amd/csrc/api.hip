@@ -202,7 +202,7 @@ SkinPlan plan_skin(const CompiledRig& r, uint32_t I, const skinrt_config& cfg, c
         auto blocks_for = [&](uint32_t look) { return skin2_blocks_per_cu(lds_for(look)); };
         p.look2 = blocks_for(1) > blocks_for(2) ? 1 : 2;
         p.lds_bytes2 = lds_for(p.look2) + (uint32_t)env.lds_pad;
-        if (p.lds_bytes2 > 64 * 1024) p.v2 = 0;
+        if (p.lds_bytes2 > kSkin2MaxLds) p.v2 = 0;
         if (r.split_joints && p.v2) {  // the short class's ring
             p.split2 = 1;
             p.jt2s = std::max<uint32_t>(1, r.split_joints_short);

@@ -69,6 +69,8 @@ struct CrowdDev {
     uint64_t* amask;       // [I][ceil(M / 64)] bit t = morph weight t is non-zero (rebuilt by every skin stage), or nullptr
 };
 
+constexpr uint32_t kSkin2MaxLds = 80 * 1024;  // dynamic LDS of a k_skin2 block: at least two blocks per CU (gfx950: 160 KiB per CU, a workgroup may take all of it)
+
 // How the skinning grid is cut (computed once per crowd by plan_skin()).
 struct SkinPlan {
     uint32_t range;     // instances per block (one block = one vertex tile x one instance range)

@@ -8,7 +8,7 @@
 // in LDS (rig_compile builds per-tile joint lists and rewrites the vertex indices to list
 // positions); morph deltas of the (tile, target) pairs with a non-zero weight reach the waves
 // through LDS slots.  Three kernels share the arithmetic below:
-//   k_skin2     tiles with <= 42 joints, <= 2 weight sets: four self-staging waves per block
+//   k_skin2     tiles with <= 64 joints, <= 2 weight sets: four self-staging waves per block
 //   k_skin_fix  the (tile, instance) pairs k_skin2 hands over (3+ active pairs; every instance of the few tiles whose long
 //               joint lists would size k_skin2's palette ring)
 //   k_skin      everything else: four compute waves + one loader wave
@@ -1204,7 +1204,7 @@ __device__ __forceinline__ float wave_bounds_packed(const float (&v)[3], bool up
 
 constexpr uint32_t kSkin2Threads = 256;
 
-// LONG: tiles with 22 .. kSkin2MaxJoints joints (a wave then moves its palette rows with up to four LDS-DMA instructions instead of two)
+// LONG: tiles with 22 .. kSkin2MaxJoints joints (a wave then moves its palette rows with up to six LDS-DMA instructions instead of two)
 template <int AR, int K, int LOOK, bool SKIP, bool SPARSE, bool LONG>
 __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) void k_skin2(const RigDev rig, const CrowdDev cr, const SkinPlan plan) {
     extern __shared__ float4 smem[];
@@ -1406,14 +1406,17 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
     }
     const uint32_t ninf = (SKINRT_EXP & 8) ? (wave + 1) * K : (SKIP ? wave_influences<K>(w) : 4u * K);
     // palette pieces this lane moves: piece c = (list position c / 6, 16-byte quarter c % 6), c = lane and lane + 64
-    const uint32_t npieces = jcnt * 6;  // <= 126 (LONG: <= 252)
+    const uint32_t npieces = jcnt * 6;  // <= 126 (LONG: <= 384)
     uint32_t joff0 = 0, joff1 = 0;      // byte offsets inside one instance's palette
     if (lane < npieces) joff0 = (rig.tile_joints[jstart + lane / 6] * 6 + lane % 6) * 16;
     if (lane + 64 < npieces) joff1 = (rig.tile_joints[jstart + (lane + 64) / 6] * 6 + (lane + 64) % 6) * 16;
-    uint32_t joff2 = 0, joff3 = 0;  // (LONG: pieces 128 .. 251)
+    uint32_t joffx[4] = {0, 0, 0, 0};  // (LONG: pieces 128 .. 383)
     if constexpr (LONG) {
-        if (lane + 128 < npieces) joff2 = (rig.tile_joints[jstart + (lane + 128) / 6] * 6 + (lane + 128) % 6) * 16;
-        if (lane + 192 < npieces) joff3 = (rig.tile_joints[jstart + (lane + 192) / 6] * 6 + (lane + 192) % 6) * 16;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t c = lane + 128 + 64 * q;
+            if (c < npieces) joffx[q] = (rig.tile_joints[jstart + c / 6] * 6 + c % 6) * 16;
+        }
     }
     const Outputs out{cr.pos, cr.nrm, cr.tan};
     const uint32_t olb = v * 12;
@@ -1442,8 +1445,12 @@ __global__ __launch_bounds__(kSkin2Threads, (K == 1 ? SKINRT_BLOCKS_K1 : 4)) voi
         }
         if constexpr (LONG) {
             if (npieces > 128) {  // wave-uniform.  (More requests per instance only make the counted waits more conservative: they count stores.)
-                if (lane + 128 < npieces) { const uint32_t lds2 = lds0 + 2048; SKINRT_GLDS_AT(joff2, gbase, lds2); }
-                if (lane + 192 < npieces) { const uint32_t lds3 = lds0 + 3072; SKINRT_GLDS_AT(joff3, gbase, lds3); }
+                if (lane + 128 < npieces) { const uint32_t lds2 = lds0 + 2048; SKINRT_GLDS_AT(joffx[0], gbase, lds2); }
+                if (lane + 192 < npieces) { const uint32_t lds3 = lds0 + 3072; SKINRT_GLDS_AT(joffx[1], gbase, lds3); }
+                if (npieces > 256) {
+                    if (lane + 256 < npieces) { const uint32_t lds4 = lds0 + 4096; SKINRT_GLDS_AT(joffx[2], gbase, lds4); }
+                    if (lane + 320 < npieces) { const uint32_t lds5 = lds0 + 5120; SKINRT_GLDS_AT(joffx[3], gbase, lds5); }
+                }
             }
         }
     };
@@ -1644,7 +1651,7 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         (uint64_t)plan.ranges_per_chunk * (8 / plan.tile_chunks) < plan.ranges)
         return hipErrorInvalidValue;
     if (plan.v2 && (plan.range2 == 0 || plan.range2 > kSkin2Range || (uint64_t)plan.ranges2 * plan.range2 < cr.I ||
-                    plan.lds_bytes2 > 64 * 1024 || rig.K > 2 || plan.jt2 == 0 || plan.jt2 > kSkin2MaxJoints || (plan.fix_pieces != 128 && plan.fix_pieces != 256 && plan.fix_pieces != 384) || plan.look2 < 1 || plan.look2 > 2 ||
+                    plan.lds_bytes2 > kSkin2MaxLds || rig.K > 2 || plan.jt2 == 0 || plan.jt2 > kSkin2MaxJoints || (plan.fix_pieces != 128 && plan.fix_pieces != 256 && plan.fix_pieces != 384) || plan.look2 < 1 || plan.look2 > 2 ||
                     (uint64_t)plan.ranges_per_chunk2 * (8 / plan.tile_chunks) < plan.ranges2 ||
                     plan.run2 == 0 || plan.tiles_per_chunk2 % plan.run2 != 0 || plan.tiles_per_chunk2 < plan.tiles_per_chunk))
         return hipErrorInvalidValue;
@@ -1670,7 +1677,7 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         // 0.5 ms (C3).  Fork / join by events: the caller's stream sees the stage as one unit.
         // (a tile needs at least 3 pairs to hand an instance over: without such a tile there is no list to build and no
         // k_skin_fix to launch; the active-pair bit rows are k_skin2's own input either way)
-        // The tiles k_skin2 leaves to k_skin (few: joint lists over 42 entries) go the same way, in front of k_skin_fix on the
+        // The tiles k_skin2 leaves to k_skin (joint lists over 64 entries, gathered from L2; every tile on rigs with 3 - 4 weight sets) go the same way, in front of k_skin_fix on the
         // side stream, instead of as a tail behind k_skin2 (in front of k_skin2 on its own stream was measured too: slower).
         const bool lists = cr.fix && (plan.max_pairs > 2 || (plan.kinds & 8u));
         const bool want_fix = lists && !(SKINRT_ABLATE & 32);
@@ -1735,7 +1742,10 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
         const dim3 grid(8u * plan.tiles_per_chunk2 * plan.ranges_per_chunk2), block(kSkin2Threads);
 #define SKINRT_LAUNCH2(EX, KK, LL, SK)                                                                                     \
     do {                                                                                                                   \
-        if (plan.jt2 > 21) hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, true, true>), grid, block, plan.lds_bytes2, s, rig, cr, plan); /* long lists: one instantiation for dense and compacted pairs */ \
+        if (plan.jt2 > 21) {  /* long lists: one instantiation for dense and compacted pairs; over 64 KiB of LDS wants to be announced */ \
+            if (plan.lds_bytes2 > 64u * 1024u) (void)hipFuncSetAttribute((const void*)k_skin2<EX, KK, LL, SK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes2); \
+            hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, true, true>), grid, block, plan.lds_bytes2, s, rig, cr, plan);                  \
+        }                                                                                                                  \
         else if (rig.sparse_pairs) hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, true, false>), grid, block, plan.lds_bytes2, s, rig, cr, plan); \
         else hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, false, false>), grid, block, plan.lds_bytes2, s, rig, cr, plan);   \
     } while (0)

@@ -359,7 +359,7 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
         std::sort(list.begin(), list.end());
         for (uint32_t i = 0; i < list.size(); ++i) local_of[list[i]] = i;
         const bool lds = list.size() <= kTileJointCap;
-        // 2: short list (its 16-byte palette pieces fit two LDS-DMA instructions per wave, or four for 22 .. 42 joints:
+        // 2: short list (its 16-byte palette pieces fit two LDS-DMA instructions per wave, or up to six for 22 .. 64 joints:
         // the self-staging kernel), 1: fits the loader-wave kernel's LDS staging, 0: gathers from L2
         r.tile_lds[t] = lds ? (list.size() <= kSkin2MaxJoints ? 2 : 1) : 0;
         r.tile_kind_count[r.tile_lds[t]] += 1;
@@ -519,18 +519,9 @@ static void compile_impl(const skinrt_rig_desc* d, const skinrt_config* cfg, Com
     // k_skin2 sizes every block's palette ring by the LONGEST joint list among its tiles, and the ring decides how many
     // blocks a CU holds.  A few long lists — tiles that straddle two mesh sections with different skins, a hand among
     // torso tiles — must not cost every tile a resident block: if handing at most 2 % of the kernel's tiles over to
-    // k_skin_fix (kind 3: every instance of the tile goes on its work list; that kernel stages any list of up to 42
+    // k_skin_fix (kind 3: every instance of the tile goes on its work list; that kernel stages any list of up to 64
     // joints and runs beside k_skin2 in what k_skin2 leaves free) buys one, do it.
     // (C3's avatar cut into three skins: lists of 8 except three straddling tiles with 15; 4 -> 5 blocks per CU.)
-    // The same for the few tiles whose lists are too long for k_skin2 altogether (43 .. 64 joints: kind 1, the loader-wave
-    // kernel — which, for a handful of tiles, is a 0.8 ms tail of one-instance batches behind k_skin2): where they are at
-    // most 2 % of the tiles they go to k_skin_fix whole as well (it stages up to 384 palette pieces on such rigs).
-    if (K <= 2 && r.tile_kind_count[2] > 0 && r.tile_kind_count[1] > 0 && (uint64_t)r.tile_kind_count[1] * 50 <= T) {
-        for (uint32_t t = 0; t < T; ++t)
-            if (r.tile_lds[t] == 1) r.tile_lds[t] = 3;
-        r.tile_kind_count[3] += r.tile_kind_count[1];
-        r.tile_kind_count[1] = 0;
-    }
     if (K <= 2 && r.tile_kind_count[2] > 0) {
         uint32_t hist[kSkin2MaxJoints + 1] = {0};
         for (uint32_t t = 0; t < T; ++t)

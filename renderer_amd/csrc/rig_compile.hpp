@@ -11,7 +11,7 @@ namespace skinrt {
 
 constexpr uint32_t kTileVerts = 256;   // vertices per skinning tile = threads per block
 constexpr uint32_t kTileJointCap = 64; // largest tile-local joint list that is LDS-staged
-constexpr uint32_t kSkin2MaxJoints = 42;  // longest tile joint list the self-staging kernel takes: 252 16-byte palette pieces = four LDS-DMA instructions per wave
+constexpr uint32_t kSkin2MaxJoints = 64;  // longest tile joint list the self-staging kernel takes (= kTileJointCap): 384 16-byte palette pieces = six LDS-DMA instructions per wave
 constexpr uint32_t kPalFloats = 24;    // palette entry: 3x4 joint rows, 3x3 normal rows packed, 3 floats of padding
 // Joints farther than this from the origin of their bind space make the skinning sums cancel: a fused and an
 // unfused multiply-add then differ by a few ulp(extent) ~ 2.4e-7 * extent, which at 4 units reaches the
