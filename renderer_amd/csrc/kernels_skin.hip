@@ -1743,7 +1743,10 @@ hipError_t launch_skin(const RigDev& rig, const CrowdDev& cr, const SkinPlan& pl
 #define SKINRT_LAUNCH2(EX, KK, LL, SK)                                                                                     \
     do {                                                                                                                   \
         if (plan.jt2 > 21) {  /* long lists: one instantiation for dense and compacted pairs; over 64 KiB of LDS wants to be announced */ \
-            if (plan.lds_bytes2 > 64u * 1024u) (void)hipFuncSetAttribute((const void*)k_skin2<EX, KK, LL, SK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes2); \
+            if (plan.lds_bytes2 > 64u * 1024u) {                                                                          \
+                const hipError_t ae = hipFuncSetAttribute((const void*)k_skin2<EX, KK, LL, SK, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes2); \
+                if (ae != hipSuccess) return ae;                                                                           \
+            }                                                                                                              \
             hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, true, true>), grid, block, plan.lds_bytes2, s, rig, cr, plan);                  \
         }                                                                                                                  \
         else if (rig.sparse_pairs) hipLaunchKernelGGL((k_skin2<EX, KK, LL, SK, true, false>), grid, block, plan.lds_bytes2, s, rig, cr, plan); \
