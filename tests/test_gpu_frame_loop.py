@@ -155,12 +155,19 @@ def test_frame_loop_with_device_side_clocks_keeps_the_host_ahead():
         c.close(); r.close()
 
 
-def test_a_frame_is_capturable_into_a_hip_graph_and_replays_bit_for_bit():
+@pytest.mark.parametrize("long_lists", [False, True])
+def test_a_frame_is_capturable_into_a_hip_graph_and_replays_bit_for_bit(long_lists):
     """A caller with a graph-driven loop: advance_clocks + evaluate(ALL) recorded once with hipStreamBeginCapture on the
     context's stream (kernels, a memset, events and the fork / join over the library's side stream are all capturable;
     nothing is allocated once the crowd has run a frame) and replayed; clocks, vertices and bounds after five replays
-    equal those after five frames of plain stream launches."""
-    spec, rig = _rig(seed=21)
+    equal those after five frames of plain stream launches.  long_lists: tiles of about 60 joints — the skin kernel's
+    blocks then take more than 64 KiB of LDS, which the launch announces with hipFuncSetAttribute (inside the capture too)."""
+    if long_lists:
+        spec = synth.scaled(synth.tiny_spec(seed=326), nodes=80, joints=64, verts=1400, sets=1, targets=10, target_mode="dense",
+                            joint_spread=26, clips=2, keys=6, max_depth=10)
+        rig = synth.make_rig(spec)
+    else:
+        spec, rig = _rig(seed=21)
     n = 513
     crowd = synth.make_crowd(spec, rig, instances=n)
     dev = DeviceBuffers()
@@ -169,6 +176,7 @@ def test_a_frame_is_capturable_into_a_hip_graph_and_replays_bit_for_bit():
     with api.Context() as ctx:
         r = api.Rig(ctx, rig)
         c = api.Crowd(ctx, r, n)
+        assert not long_lists or r.info.max_tile_joints > 56, r.info.max_tile_joints
         c.set_morph_weights(crowd.morph_weights)
         c.set_clocks(crowd.tau, crowd.clip_id)
         for _ in range(5):
