@@ -178,6 +178,37 @@ int main() {
             CHECK(c.split_joints == 0);
         }
     }
+    // every tile on a window of 50 joints (one or two weight sets): all of them the self-staging kernel's (kind 2, up to
+    // kSkin2MaxJoints = 64 entries), none the loader-wave kernel's (kind 1); a window of 70: staged by nobody (kind 0)
+    for (uint32_t window : {50u, 70u}) {
+        const uint32_t J = 72, tiles = 8, V = tiles * kTileVerts;
+        std::vector<int32_t> parent(J, -1);
+        std::vector<float> t(J * 3, 0.0f), rq(J * 4, 0.0f), sc(J * 3, 1.0f);
+        for (uint32_t n = 0; n < J; ++n) rq[n * 4 + 3] = 1.0f;
+        std::vector<uint32_t> jn(J);
+        for (uint32_t n = 0; n < J; ++n) jn[n] = n;
+        std::vector<float> pos(V * 3, 0.5f), nrm(V * 3, 0.0f), tan(V * 3, 0.0f), w(V * 4, 0.25f);
+        std::vector<uint16_t> j(V * 4);
+        for (uint32_t v = 0; v < V; ++v)
+            for (int a = 0; a < 4; ++a) j[v * 4 + a] = (uint16_t)((v * 3 + a * 11) % window);
+        const uint16_t* jp[1] = {j.data()};
+        const float* wp[1] = {w.data()};
+        skinrt_rig_desc d{};
+        d.struct_size = sizeof(d);
+        d.node_count = J; d.parent = parent.data(); d.translation = t.data(); d.rotation = rq.data(); d.scale = sc.data();
+        d.joint_count = J; d.joint_node = jn.data();
+        d.vertex_count = V; d.position = pos.data(); d.normal = nrm.data(); d.tangent = tan.data(); d.tangent_stride = 3;
+        d.set_count = 1; d.joints = jp; d.weights = wp;
+        CompiledRig c;
+        CHECK(compile_rig(&d, nullptr, c, why) == SKINRT_OK);
+        CHECK(c.tile_kind_count[1] == 0);
+        if (window <= kSkin2MaxJoints) {
+            CHECK(c.max_tile_joints2 == window);
+            CHECK(c.tile_kind_count[2] + c.tile_kind_count[3] == tiles && c.tile_kind_count[2] >= tiles - 1);
+        } else {
+            CHECK(c.tile_kind_count[0] == tiles);
+        }
+    }
     if (failures) { std::printf("rig compiler selftest: %d check(s) failed (%s)\n", failures, why.c_str()); return 1; }
     std::printf("rig compiler selftest ok\n");
     return 0;
